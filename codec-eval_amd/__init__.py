@@ -1,0 +1,533 @@
+"""codec-eval_amd — MI355X (gfx950) backend for the perceptual-metric hot path of imazen/codec-eval.
+
+The product is ``libce_metrics_hip.so`` (hand-written HIP kernels behind the C ABI declared in
+``include/ce_metrics.h``).  This module is the thin ctypes binding used by the tests, bench.py and
+Python callers; every metric call goes through the C ABI and there is NO CPU fallback: if the shared
+library is missing or no HIP device is visible the call raises.
+
+Import name: the directory is ``codec-eval_amd`` (hyphen, as the repo layout prescribes); use
+``import codec_eval_amd`` (the shim module at the repo root) or
+``importlib.import_module("codec-eval_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libce_metrics_hip.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+# ---- enums of include/ce_metrics.h ---------------------------------------------------------
+CE_OK, CE_ERR_DIM_MISMATCH, CE_ERR_BAD_LENGTH, CE_ERR_TOO_SMALL, CE_ERR_BACKEND, CE_ERR_INVALID_ARG = range(6)
+METRIC_DSSIM, METRIC_SSIMULACRA2, METRIC_BUTTERAUGLI, METRIC_PSNR = 1, 2, 4, 8
+FLAG_XYB_ROUNDTRIP = 1
+DEFAULT_INTENSITY_TARGET = 80.0
+
+_STATUS_NAMES = {
+    CE_ERR_DIM_MISMATCH: "DimensionMismatch",
+    CE_ERR_BAD_LENGTH: "MetricCalculation(invalid image size)",
+    CE_ERR_TOO_SMALL: "MetricCalculation(image too small)",
+    CE_ERR_BACKEND: "MetricCalculation(backend)",
+    CE_ERR_INVALID_ARG: "InvalidArgument",
+}
+
+
+class CeScores(C.Structure):
+    _fields_ = [
+        ("dssim", C.c_double),
+        ("ssimulacra2", C.c_double),
+        ("butteraugli", C.c_double),
+        ("psnr", C.c_double),
+        ("valid", C.c_uint32),
+        ("status", C.c_int32),
+    ]
+
+
+class CePairDesc(C.Structure):
+    _fields_ = [
+        ("reference", C.c_void_p),
+        ("reference_len", C.c_size_t),
+        ("test", C.c_void_p),
+        ("test_len", C.c_size_t),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+    ]
+
+
+class CodecEvalError(RuntimeError):
+    """Mirrors codec_eval::Error for this path (src/error.rs:31-49)."""
+
+    def __init__(self, status: int, message: str = ""):
+        self.status = status
+        self.kind = _STATUS_NAMES.get(status, f"status {status}")
+        super().__init__(f"{self.kind}: {message}" if message else self.kind)
+
+
+class DimensionMismatch(CodecEvalError):
+    pass
+
+
+class MetricCalculation(CodecEvalError):
+    pass
+
+
+def _raise(status: int, message: str):
+    if status == CE_ERR_DIM_MISMATCH:
+        raise DimensionMismatch(status, message)
+    if status in (CE_ERR_BAD_LENGTH, CE_ERR_TOO_SMALL, CE_ERR_BACKEND):
+        raise MetricCalculation(status, message)
+    raise CodecEvalError(status, message)
+
+
+_lib: Optional[C.CDLL] = None
+
+# (name, restype, argtypes) — must list every function include/ce_metrics.h declares
+_vp, _u8p, _sz, _u32, _f32, _i = C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_float, C.c_int
+_dp = C.POINTER(C.c_double)
+_PROTOTYPES = [
+    ("ce_version", C.c_char_p, []),
+    ("ce_device_count", _i, []),
+    ("ce_ctx_create", _i, [_i, C.POINTER(_vp)]),
+    ("ce_ctx_create_on_stream", _i, [_i, _vp, C.POINTER(_vp)]),
+    ("ce_ctx_destroy", None, [_vp]),
+    ("ce_ctx_synchronize", _i, [_vp]),
+    ("ce_ctx_stream", _vp, [_vp]),
+    ("ce_last_error", C.c_char_p, [_vp]),
+    ("ce_calculate_psnr", _i, [_vp, _u8p, _sz, _u8p, _sz, _sz, _sz, _dp]),
+    ("ce_calculate_ssimulacra2", _i, [_vp, _u8p, _sz, _u8p, _sz, _sz, _sz, _dp]),
+    ("ce_calculate_dssim", _i, [_vp, _u8p, _sz, _u8p, _sz, _sz, _sz, _dp]),
+    ("ce_calculate_butteraugli", _i, [_vp, _u8p, _sz, _u8p, _sz, _sz, _sz, _f32, _dp]),
+    ("ce_xyb_roundtrip", _i, [_vp, _u8p, _sz, _sz, _sz, _u8p]),
+    ("ce_rgb8_to_dssim_image", _i, [_vp, _u8p, _sz, _sz, _sz, _vp]),
+    ("ce_eval_pair", _i, [_vp, _u8p, _sz, _u8p, _sz, _u32, _u32, _u32, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_eval_batch", _i, [_vp, _sz, C.POINTER(CePairDesc), _u32, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_batch_create", _i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    ("ce_batch_destroy", None, [_vp]),
+    ("ce_batch_set_reference", _i, [_vp, _u32, _u8p, _sz]),
+    ("ce_batch_set_test", _i, [_vp, _u32, _u32, _u8p, _sz]),
+    ("ce_batch_reference_slab", _vp, [_vp]),
+    ("ce_batch_test_slab", _vp, [_vp]),
+    ("ce_batch_bind_pair", _i, [_vp, _u32, _u32]),
+    ("ce_batch_run", _i, [_vp, _u32, _u32, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_batch_launch", _i, [_vp, _u32, _u32, _u32, _f32]),
+    ("ce_batch_collect", _i, [_vp, _u32, C.POINTER(CeScores)]),
+    ("ce_ref_create", _i, [_vp, _u8p, _sz, _u32, _u32, _u32, C.POINTER(_vp)]),
+    ("ce_ref_compare", _i, [_vp, _u8p, _sz, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_ref_destroy", None, [_vp]),
+    ("ce_prof_enable", _i, [_vp, _i]),
+    ("ce_prof_reset", _i, [_vp]),
+    ("ce_prof_count", _i, [_vp]),
+    ("ce_prof_get", _i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), _dp]),
+    ("ce_timer_start", _i, [_vp]),
+    ("ce_timer_stop", _i, [_vp, _dp]),
+    ("ce_debug_ssim2_planes", _i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
+    ("ce_debug_ssim2_limit_scales", _i, [_vp, _i]),
+    ("ce_debug_ssim2_averages", _i, [_vp, _u32, _dp, C.POINTER(_i)]),
+]
+ABI_SYMBOLS = [p[0] for p in _PROTOTYPES]
+
+
+def lib() -> C.CDLL:
+    """Load libce_metrics_hip.so (built by __graft_entry__.build() / codec-eval_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback."
+            )
+        _lib = C.CDLL(LIB_PATH)
+        for name, restype, argtypes in _PROTOTYPES:
+            fn = getattr(_lib, name)  # AttributeError here = ABI symbol missing
+            fn.restype = restype
+            fn.argtypes = argtypes
+    return _lib
+
+
+def version() -> str:
+    return lib().ce_version().decode()
+
+
+def device_count() -> int:
+    return int(lib().ce_device_count())
+
+
+def _buf(a) -> np.ndarray:
+    """Borrowed view as a flat contiguous u8 array (copy only if the input is not already one)."""
+    arr = np.asarray(a)
+    if arr.dtype != np.uint8:
+        raise TypeError("pixel buffers must be uint8")
+    return np.ascontiguousarray(arr).reshape(-1)
+
+
+# ---- MetricConfig / MetricResult mirrors (src/metrics/mod.rs:46-149) -----------------------
+@dataclass
+class MetricConfig:
+    dssim: bool = False
+    ssimulacra2: bool = False
+    butteraugli: bool = False
+    psnr: bool = False
+    xyb_roundtrip: bool = False
+
+    @staticmethod
+    def all() -> "MetricConfig":
+        return MetricConfig(True, True, True, True, False)
+
+    @staticmethod
+    def fast() -> "MetricConfig":
+        return MetricConfig(psnr=True)
+
+    @staticmethod
+    def perceptual() -> "MetricConfig":
+        return MetricConfig(True, True, True, False, False)
+
+    @staticmethod
+    def perceptual_xyb() -> "MetricConfig":
+        return MetricConfig(True, True, True, False, True)
+
+    @staticmethod
+    def ssimulacra2_only() -> "MetricConfig":
+        return MetricConfig(ssimulacra2=True)
+
+    def with_xyb_roundtrip(self) -> "MetricConfig":
+        return MetricConfig(self.dssim, self.ssimulacra2, self.butteraugli, self.psnr, True)
+
+    @property
+    def mask(self) -> int:
+        return (
+            (METRIC_DSSIM if self.dssim else 0)
+            | (METRIC_SSIMULACRA2 if self.ssimulacra2 else 0)
+            | (METRIC_BUTTERAUGLI if self.butteraugli else 0)
+            | (METRIC_PSNR if self.psnr else 0)
+        )
+
+    @property
+    def flags(self) -> int:
+        return FLAG_XYB_ROUNDTRIP if self.xyb_roundtrip else 0
+
+
+PERCEPTION_LEVELS = ("Imperceptible", "Marginal", "Subtle", "Noticeable", "Degraded")
+
+
+def perception_from_dssim(d: float) -> str:  # src/metrics/mod.rs:189-201
+    for level, t in zip(PERCEPTION_LEVELS, (0.0003, 0.0007, 0.0015, 0.003)):
+        if d < t:
+            return level
+    return "Degraded"
+
+
+def perception_from_ssimulacra2(s: float) -> str:  # mod.rs:206-218
+    for level, t in zip(PERCEPTION_LEVELS, (90.0, 80.0, 70.0, 50.0)):
+        if s > t:
+            return level
+    return "Degraded"
+
+
+def perception_from_butteraugli(b: float) -> str:  # mod.rs:223-235
+    for level, t in zip(PERCEPTION_LEVELS, (1.0, 2.0, 3.0, 5.0)):
+        if b < t:
+            return level
+    return "Degraded"
+
+
+@dataclass
+class MetricResult:
+    dssim: Optional[float] = None
+    ssimulacra2: Optional[float] = None
+    butteraugli: Optional[float] = None
+    psnr: Optional[float] = None
+
+    def perception_level(self) -> Optional[str]:  # mod.rs:154-156 (DSSIM only)
+        return None if self.dssim is None else perception_from_dssim(self.dssim)
+
+    @staticmethod
+    def from_c(s: CeScores) -> "MetricResult":
+        return MetricResult(
+            s.dssim if s.valid & METRIC_DSSIM else None,
+            s.ssimulacra2 if s.valid & METRIC_SSIMULACRA2 else None,
+            s.butteraugli if s.valid & METRIC_BUTTERAUGLI else None,
+            s.psnr if s.valid & METRIC_PSNR else None,
+        )
+
+
+class Context:
+    """One device + one stream (GpuSsim2::new, crates/codec-iter/src/gpu.rs:40)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        L = lib()
+        rc = L.ce_ctx_create_on_stream(device, stream, C.byref(self._h)) if stream else L.ce_ctx_create(device, C.byref(self._h))
+        if rc != CE_OK:
+            msg = (L.ce_last_error(None) or b"").decode()
+            self._h = C.c_void_p()
+            _raise(rc, msg)
+        self.device = device
+
+    # -- lifetime
+    def close(self):
+        if self._h:
+            lib().ce_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _err(self) -> str:
+        return (lib().ce_last_error(self._h) or b"").decode()
+
+    def _check(self, rc: int):
+        if rc != CE_OK:
+            _raise(rc, self._err())
+
+    @property
+    def stream(self) -> int:
+        return int(lib().ce_ctx_stream(self._h) or 0)
+
+    def synchronize(self):
+        self._check(lib().ce_ctx_synchronize(self._h))
+
+    # -- leaf calls, same names / argument order as the reference
+    def _leaf(self, fn, reference, test, width, height, *extra) -> float:
+        r, t = _buf(reference), _buf(test)
+        out = C.c_double()
+        self._check(fn(self._h, r.ctypes.data, r.size, t.ctypes.data, t.size, width, height, *extra, C.byref(out)))
+        return out.value
+
+    def calculate_psnr(self, reference, test, width: int, height: int) -> float:
+        """calculate_psnr, src/metrics/mod.rs:312 (the reference panics on bad lengths; this raises)."""
+        return self._leaf(lib().ce_calculate_psnr, reference, test, width, height)
+
+    def calculate_ssimulacra2(self, reference, test, width: int, height: int) -> float:
+        """calculate_ssimulacra2, src/metrics/ssimulacra2.rs:59."""
+        return self._leaf(lib().ce_calculate_ssimulacra2, reference, test, width, height)
+
+    def calculate_dssim(self, reference, test, width: int, height: int) -> float:
+        """rgb8_to_dssim_image x2 + calculate_dssim, src/metrics/dssim.rs:102,40."""
+        return self._leaf(lib().ce_calculate_dssim, reference, test, width, height)
+
+    def calculate_butteraugli(self, reference, test, width: int, height: int) -> float:
+        """calculate_butteraugli, src/metrics/butteraugli.rs:45."""
+        return self._leaf(lib().ce_calculate_butteraugli, reference, test, width, height, DEFAULT_INTENSITY_TARGET)
+
+    def calculate_butteraugli_with_intensity(self, reference, test, width: int, height: int, intensity_target: float) -> float:
+        """calculate_butteraugli_with_intensity, src/metrics/butteraugli.rs:99."""
+        return self._leaf(lib().ce_calculate_butteraugli, reference, test, width, height, float(intensity_target))
+
+    def xyb_roundtrip(self, rgb, width: int, height: int) -> np.ndarray:
+        """xyb_roundtrip, src/metrics/xyb.rs:225."""
+        r = _buf(rgb)
+        out = np.empty(r.size, np.uint8)
+        self._check(lib().ce_xyb_roundtrip(self._h, r.ctypes.data, r.size, width, height, out.ctypes.data))
+        return out
+
+    def rgb8_to_dssim_image(self, rgb, width: int, height: int) -> np.ndarray:
+        """rgb8_to_dssim_image, src/metrics/dssim.rs:102 -> (h, w, 4) float32, a = 1.0."""
+        r = _buf(rgb)
+        out = np.empty((height, width, 4), np.float32)
+        self._check(lib().ce_rgb8_to_dssim_image(self._h, r.ctypes.data, r.size, width, height, out.ctypes.data))
+        return out
+
+    # -- dispatcher
+    def calculate_metrics(self, reference, test, width: int, height: int, config: MetricConfig,
+                          intensity_target: float = DEFAULT_INTENSITY_TARGET) -> MetricResult:
+        """EvalSession::calculate_metrics, src/eval/session.rs:437-497."""
+        r, t = _buf(reference), _buf(test)
+        s = CeScores()
+        self._check(lib().ce_eval_pair(self._h, r.ctypes.data, r.size, t.ctypes.data, t.size, width, height,
+                                       config.mask, config.flags, intensity_target, C.byref(s)))
+        return MetricResult.from_c(s)
+
+    def eval_batch(self, pairs: Sequence[tuple], config: MetricConfig,
+                   intensity_target: float = DEFAULT_INTENSITY_TARGET) -> List[CeScores]:
+        """pairs: (reference, test, width, height).  The (codec x quality) grid of session.rs:375-376."""
+        n = len(pairs)
+        descs = (CePairDesc * n)()
+        keep = []
+        for i, (ref, test, w, h) in enumerate(pairs):
+            r, t = _buf(ref), _buf(test)
+            keep.append((r, t))
+            descs[i] = CePairDesc(r.ctypes.data, r.size, t.ctypes.data, t.size, w, h)
+        out = (CeScores * n)()
+        self._check(lib().ce_eval_batch(self._h, n, descs, config.mask, config.flags, intensity_target, out))
+        return list(out)
+
+    # -- measurement hooks
+    def prof_enable(self, on: bool = True):
+        self._check(lib().ce_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._check(lib().ce_prof_reset(self._h))
+
+    def prof_stats(self) -> dict:
+        L = lib()
+        out = {}
+        for i in range(L.ce_prof_count(self._h)):
+            name, n, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+            self._check(L.ce_prof_get(self._h, i, C.byref(name), C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (int(n.value), float(ms.value))
+        return out
+
+    def timer_start(self):
+        self._check(lib().ce_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double()
+        self._check(lib().ce_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+
+class Batch:
+    """HBM-resident grid of (reference, test) pairs of one shape (ce_batch_*)."""
+
+    def __init__(self, ctx: Context, width: int, height: int, max_refs: int, max_pairs: int):
+        self.ctx, self.width, self.height = ctx, width, height
+        self.max_refs, self.max_pairs = max_refs, max_pairs
+        self._h = C.c_void_p()
+        ctx._check(lib().ce_batch_create(ctx._h, width, height, max_refs, max_pairs, C.byref(self._h)))
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib().ce_batch_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_reference(self, ref_index: int, rgb):
+        r = _buf(rgb)
+        self.ctx._check(lib().ce_batch_set_reference(self._h, ref_index, r.ctypes.data, r.size))
+
+    def set_test(self, pair_index: int, ref_index: int, rgb):
+        t = _buf(rgb)
+        self.ctx._check(lib().ce_batch_set_test(self._h, pair_index, ref_index, t.ctypes.data, t.size))
+
+    def bind_pair(self, pair_index: int, ref_index: int):
+        self.ctx._check(lib().ce_batch_bind_pair(self._h, pair_index, ref_index))
+
+    @property
+    def reference_slab(self) -> int:
+        return int(lib().ce_batch_reference_slab(self._h))
+
+    @property
+    def test_slab(self) -> int:
+        return int(lib().ce_batch_test_slab(self._h))
+
+    def run(self, n_pairs: int, config: MetricConfig, intensity_target: float = DEFAULT_INTENSITY_TARGET) -> List[CeScores]:
+        out = (CeScores * n_pairs)()
+        self.ctx._check(lib().ce_batch_run(self._h, n_pairs, config.mask, config.flags, intensity_target, out))
+        return list(out)
+
+    def launch(self, n_pairs: int, config: MetricConfig, intensity_target: float = DEFAULT_INTENSITY_TARGET):
+        self.ctx._check(lib().ce_batch_launch(self._h, n_pairs, config.mask, config.flags, intensity_target))
+
+    def collect(self, n_pairs: int) -> List[CeScores]:
+        out = (CeScores * n_pairs)()
+        self.ctx._check(lib().ce_batch_collect(self._h, n_pairs, out))
+        return list(out)
+
+    # -- test hooks
+    def debug_limit_scales(self, n: int):
+        self.ctx._check(lib().ce_debug_ssim2_limit_scales(self._h, n))
+
+    def debug_planes(self, scale: int, which: int, channel: int = 0) -> np.ndarray:
+        nplanes = 5 if which == 4 else 3
+        buf = np.empty(nplanes * self.width * self.height, np.float32)
+        w, h = C.c_uint32(), C.c_uint32()
+        self.ctx._check(lib().ce_debug_ssim2_planes(self._h, scale, which, channel, buf.ctypes.data, buf.size,
+                                                     C.byref(w), C.byref(h)))
+        return buf[: nplanes * w.value * h.value].reshape(nplanes, h.value, w.value).copy()
+
+    def debug_averages(self, pair_index: int) -> np.ndarray:
+        avg = np.zeros((6, 3, 6), np.float64)
+        ns = C.c_int()
+        self.ctx._check(lib().ce_debug_ssim2_averages(self._h, pair_index, avg.ctypes.data_as(_dp), C.byref(ns)))
+        return avg[: ns.value].copy()
+
+
+class ReferenceHandle:
+    """Ssimulacra2Reference::{new, compare} (crates/codec-iter/src/eval.rs:138-149, 83-89)."""
+
+    def __init__(self, ctx: Context, reference, width: int, height: int, xyb_roundtrip: bool = False):
+        self.ctx = ctx
+        r = _buf(reference)
+        self._h = C.c_void_p()
+        ctx._check(lib().ce_ref_create(ctx._h, r.ctypes.data, r.size, width, height,
+                                       FLAG_XYB_ROUNDTRIP if xyb_roundtrip else 0, C.byref(self._h)))
+
+    def compare(self, test, config: MetricConfig = None, intensity_target: float = DEFAULT_INTENSITY_TARGET) -> MetricResult:
+        config = config or MetricConfig.ssimulacra2_only()
+        t = _buf(test)
+        s = CeScores()
+        self.ctx._check(lib().ce_ref_compare(self._h, t.ctypes.data, t.size, config.mask, intensity_target, C.byref(s)))
+        return MetricResult.from_c(s)
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib().ce_ref_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- eval helpers (src/eval/helpers.rs) ----------------------------------------------------
+class QualityBelowThreshold(CodecEvalError):
+    def __init__(self, metric: str, value: float, threshold: float):
+        RuntimeError.__init__(self, f"{metric} quality below threshold: {value} (threshold: {threshold})")
+        self.status, self.kind = -1, "QualityBelowThreshold"
+        self.metric, self.value, self.threshold = metric, value, threshold
+
+
+def _as_rgb8(img) -> np.ndarray:
+    a = np.asarray(img)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise TypeError("expected an (h, w, 3) uint8 image")
+    return a
+
+
+def evaluate_single(ctx: Context, reference, encoded, config: MetricConfig) -> MetricResult:
+    """evaluate_single, src/eval/helpers.rs:105-173: (h, w, 3) uint8 images."""
+    r, e = _as_rgb8(reference), _as_rgb8(encoded)
+    if r.shape != e.shape:  # helpers.rs:111-116
+        raise DimensionMismatch(CE_ERR_DIM_MISMATCH, f"expected {(r.shape[1], r.shape[0])}, got {(e.shape[1], e.shape[0])}")
+    return ctx.calculate_metrics(r, e, r.shape[1], r.shape[0], config)
+
+
+def assert_quality(ctx: Context, reference, encoded, min_ssimulacra2: Optional[float], max_dssim: Optional[float]) -> None:
+    """assert_quality, src/eval/helpers.rs:212-255."""
+    cfg = MetricConfig(dssim=max_dssim is not None, ssimulacra2=min_ssimulacra2 is not None)
+    res = evaluate_single(ctx, reference, encoded, cfg)
+    if min_ssimulacra2 is not None and res.ssimulacra2 is not None and res.ssimulacra2 < min_ssimulacra2:
+        raise QualityBelowThreshold("SSIMULACRA2", res.ssimulacra2, min_ssimulacra2)
+    if max_dssim is not None and res.dssim is not None and res.dssim > max_dssim:
+        raise QualityBelowThreshold("DSSIM", res.dssim, max_dssim)
+
+
+def assert_perception_level(ctx: Context, reference, encoded, min_level: str) -> None:
+    """assert_perception_level, src/eval/helpers.rs:291-321 (DSSIM only, ordinal compare)."""
+    res = evaluate_single(ctx, reference, encoded, MetricConfig(dssim=True))
+    if res.dssim is not None:
+        actual = PERCEPTION_LEVELS.index(perception_from_dssim(res.dssim))
+        want = PERCEPTION_LEVELS.index(min_level)
+        if actual > want:
+            raise QualityBelowThreshold(f"PerceptionLevel (DSSIM {res.dssim:.6f})", float(actual), float(want))

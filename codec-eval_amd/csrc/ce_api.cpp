@@ -1,0 +1,674 @@
+// Host runtime behind the C ABI (include/ce_metrics.h): contexts, the HBM-resident pair
+// grid, shape bucketing for mixed batches, input validation with the reference's error
+// kinds, profiling hooks.  All device work is in the .hip files; there is no CPU compute
+// path here — if HIP is unavailable every entry point fails with CE_ERR_BACKEND.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "ce_internal.h"
+
+namespace {
+
+thread_local std::string g_err_noctx;
+
+int fail(ce_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg; else g_err_noctx = msg;
+    return code;
+}
+
+// validation order of calculate_ssimulacra2 / calculate_butteraugli
+// (src/metrics/ssimulacra2.rs:65-82, src/metrics/butteraugli.rs:51-67)
+int validate_pair(ce_ctx *ctx, size_t ref_len, size_t test_len, size_t w, size_t h)
+{
+    if (ref_len != test_len)
+        return fail(ctx, CE_ERR_DIM_MISMATCH, "Dimension mismatch: reference " + std::to_string(ref_len) +
+                                                   " bytes, test " + std::to_string(test_len) + " bytes");
+    if (ref_len != w * h * 3)
+        return fail(ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(w * h * 3) +
+                                                 " bytes, got " + std::to_string(ref_len));
+    return CE_OK;
+}
+
+double psnr_from_sse(unsigned long long sse, size_t w, size_t h)
+{
+    // src/metrics/mod.rs:317,324-330
+    const double pixel_count = (double)(w * h * 3);
+    const double mse = (double)sse / pixel_count;
+    if (mse == 0.0) return INFINITY;
+    return 10.0 * std::log10(255.0 * 255.0 / mse);
+}
+
+}  // namespace
+
+// ---- profiling -----------------------------------------------------------------------------
+
+int ce_prof_begin(ce_ctx *ctx, const char *name)
+{
+    int idx = -1;
+    for (size_t i = 0; i < ctx->stats.size(); i++)
+        if (ctx->stats[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) {
+        ctx->stats.push_back(ce_kernel_stat{name, 0, 0.0});
+        idx = (int)ctx->stats.size() - 1;
+    }
+    ce_ctx::pending pd{idx, nullptr, nullptr};
+    for (hipEvent_t *e : {&pd.e0, &pd.e1}) {
+        if (!ctx->event_pool.empty()) {
+            *e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else if (hipEventCreate(e) != hipSuccess) {
+            return -1;
+        }
+    }
+    hipEventRecord(pd.e0, ctx->stream);
+    ctx->pend.push_back(pd);
+    return (int)ctx->pend.size() - 1;
+}
+
+void ce_prof_end(ce_ctx *ctx, int token) { hipEventRecord(ctx->pend[token].e1, ctx->stream); }
+
+static void prof_drain(ce_ctx *ctx)
+{
+    if (ctx->pend.empty()) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto &pd : ctx->pend) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pd.e0, pd.e1) == hipSuccess) {
+            ctx->stats[pd.stat].launches++;
+            ctx->stats[pd.stat].total_ms += ms;
+        }
+        ctx->event_pool.push_back(pd.e0);
+        ctx->event_pool.push_back(pd.e1);
+    }
+    ctx->pend.clear();
+}
+
+extern "C" {
+
+const char *ce_version(void) { return "codec-eval_amd 0.1.0 (gfx950)"; }
+
+int ce_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int ce_ctx_create_on_stream(int device, void *hip_stream, ce_ctx **out)
+{
+    if (!out) return CE_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, CE_ERR_BACKEND, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(nullptr, CE_ERR_INVALID_ARG, "device index out of range");
+    ce_ctx *ctx = new (std::nothrow) ce_ctx();
+    if (!ctx) return CE_ERR_BACKEND;
+    ctx->device = device;
+    auto bail = [&](const char *what, hipError_t e) {
+        g_err_noctx = std::string(what) + ": " + hipGetErrorString(e);
+        delete ctx;
+        return CE_ERR_BACKEND;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreate", e);
+    }
+    float lut[256];
+    if ((e = hipMalloc(&ctx->d_lut_ssim2, sizeof(lut))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&ctx->d_lut_powf, sizeof(lut))) != hipSuccess) return bail("hipMalloc", e);
+    ce_build_srgb_lut_f64(lut);
+    if ((e = hipMemcpy(ctx->d_lut_ssim2, lut, sizeof(lut), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail("hipMemcpy", e);
+    ce_build_srgb_lut_powf(lut);
+    if ((e = hipMemcpy(ctx->d_lut_powf, lut, sizeof(lut), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail("hipMemcpy", e);
+    float thresh[256];
+    if (!ce_build_xyb_srgb_thresholds(thresh)) {
+        g_err_noctx = "host powf is not monotone around an sRGB code boundary; cannot build the XYB table";
+        delete ctx;
+        return CE_ERR_BACKEND;
+    }
+    if ((e = hipMalloc(&ctx->d_xyb_thresh, sizeof(thresh))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(ctx->d_xyb_thresh, thresh, sizeof(thresh), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail("hipMemcpy", e);
+    if ((e = hipEventCreate(&ctx->t0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&ctx->t1)) != hipSuccess) return bail("hipEventCreate", e);
+    *out = ctx;
+    return CE_OK;
+}
+
+int ce_ctx_create(int device, ce_ctx **out) { return ce_ctx_create_on_stream(device, nullptr, out); }
+
+void ce_ctx_destroy(ce_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    for (auto &kv : ctx->shape_pool) ce_batch_destroy(kv.second);
+    ctx->shape_pool.clear();
+    for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
+    if (ctx->t0) hipEventDestroy(ctx->t0);
+    if (ctx->t1) hipEventDestroy(ctx->t1);
+    hipFree(ctx->d_lut_ssim2);
+    hipFree(ctx->d_lut_powf);
+    hipFree(ctx->d_xyb_thresh);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int ce_ctx_synchronize(ce_ctx *ctx)
+{
+    if (!ctx) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CE_OK;
+}
+
+void *ce_ctx_stream(ce_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+const char *ce_last_error(const ce_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
+
+// ---- resident batch ------------------------------------------------------------------------
+
+int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_refs, uint32_t max_pairs,
+                    ce_batch **out)
+{
+    if (!ctx || !out || width == 0 || height == 0 || max_refs == 0 || max_pairs == 0) return CE_ERR_INVALID_ARG;
+    *out = nullptr;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    ce_batch *b = new (std::nothrow) ce_batch();
+    if (!b) return CE_ERR_BACKEND;
+    b->ctx = ctx;
+    b->w = width;
+    b->h = height;
+    b->max_refs = max_refs;
+    b->max_pairs = max_pairs;
+    b->img_bytes = (size_t)width * height * 3;
+    b->h_pair_ref.assign(max_pairs, 0);
+    int rc = CE_OK;
+    auto chk = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == CE_OK) {
+            ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+            rc = CE_ERR_BACKEND;
+        }
+    };
+    // +16 bytes: the PSNR kernel reads whole 16-byte words
+    chk(hipMalloc(&b->d_refs, b->img_bytes * max_refs + 16), "hipMalloc refs");
+    chk(hipMalloc(&b->d_tests, b->img_bytes * max_pairs + 16), "hipMalloc tests");
+    chk(hipMalloc(&b->d_pair_ref, sizeof(uint32_t) * max_pairs), "hipMalloc pair_ref");
+    chk(hipMalloc(&b->d_scores, sizeof(ce_dev_scores) * max_pairs), "hipMalloc scores");
+    chk(hipHostMalloc(&b->h_scores, sizeof(ce_dev_scores) * max_pairs, hipHostMallocDefault), "hipHostMalloc scores");
+    chk(hipHostMalloc(&b->h_stage, b->img_bytes, hipHostMallocDefault), "hipHostMalloc stage");
+    if (rc == CE_OK) chk(hipMemsetAsync(b->d_scores, 0, sizeof(ce_dev_scores) * max_pairs, ctx->stream), "memset");
+    if (rc != CE_OK) {
+        ce_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return CE_OK;
+}
+
+void ce_batch_destroy(ce_batch *b)
+{
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    hipFree(b->d_refs);
+    hipFree(b->d_refs_rt);
+    hipFree(b->d_tests);
+    hipFree(b->d_pair_ref);
+    hipFree(b->d_scores);
+    if (b->h_scores) hipHostFree(b->h_scores);
+    if (b->h_stage) hipHostFree(b->h_stage);
+    for (auto &p : b->d_lin) hipFree(p);
+    hipFree(b->d_xyb);
+    hipFree(b->d_hbuf);
+    hipFree(b->d_partials);
+    hipFree(b->d_avg);
+    delete b;
+}
+
+static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src)
+{
+    ce_ctx *ctx = b->ctx;
+    // pageable source -> pinned staging -> device, ordered on the context's stream
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(b->h_stage, src, b->img_bytes);
+    CE_HIP(ctx, hipMemcpyAsync(dst, b->h_stage, b->img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CE_OK;
+}
+
+int ce_batch_set_reference(ce_batch *b, uint32_t ref_index, const uint8_t *rgb, size_t len)
+{
+    if (!b || !rgb) return CE_ERR_INVALID_ARG;
+    if (ref_index >= b->max_refs) return fail(b->ctx, CE_ERR_INVALID_ARG, "ref_index out of range");
+    if (len != b->img_bytes)
+        return fail(b->ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(b->img_bytes) +
+                                                    " bytes, got " + std::to_string(len));
+    return upload(b, b->d_refs + (size_t)ref_index * b->img_bytes, rgb);
+}
+
+int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index)
+{
+    if (!b) return CE_ERR_INVALID_ARG;
+    if (pair_index >= b->max_pairs || ref_index >= b->max_refs)
+        return fail(b->ctx, CE_ERR_INVALID_ARG, "pair/ref index out of range");
+    if (b->h_pair_ref[pair_index] != ref_index || b->pair_ref_dirty) {
+        b->h_pair_ref[pair_index] = ref_index;
+        b->pair_ref_dirty = true;
+    }
+    return CE_OK;
+}
+
+int ce_batch_set_test(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const uint8_t *rgb, size_t len)
+{
+    if (!b || !rgb) return CE_ERR_INVALID_ARG;
+    int rc = ce_batch_bind_pair(b, pair_index, ref_index);
+    if (rc != CE_OK) return rc;
+    if (len != b->img_bytes)
+        return fail(b->ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(b->img_bytes) +
+                                                    " bytes, got " + std::to_string(len));
+    return upload(b, b->d_tests + (size_t)pair_index * b->img_bytes, rgb);
+}
+
+void *ce_batch_reference_slab(ce_batch *b) { return b ? b->d_refs : nullptr; }
+void *ce_batch_test_slab(ce_batch *b) { return b ? b->d_tests : nullptr; }
+
+int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags, float intensity_target)
+{
+    if (!b) return CE_ERR_INVALID_ARG;
+    ce_ctx *ctx = b->ctx;
+    if (n_pairs == 0 || n_pairs > b->max_pairs) return fail(ctx, CE_ERR_INVALID_ARG, "n_pairs out of range");
+    const uint32_t known = CE_METRIC_DSSIM | CE_METRIC_SSIMULACRA2 | CE_METRIC_BUTTERAUGLI | CE_METRIC_PSNR;
+    if (metric_mask & ~known) return fail(ctx, CE_ERR_INVALID_ARG, "unknown metric bit");
+    (void)intensity_target;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    if (b->pair_ref_dirty) {
+        CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, b->h_pair_ref.data(), sizeof(uint32_t) * b->max_pairs,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_pair_ref is pageable
+        b->pair_ref_dirty = false;
+    }
+    uint32_t n_refs_used = 0;
+    for (uint32_t i = 0; i < n_pairs; i++) n_refs_used = std::max(n_refs_used, b->h_pair_ref[i] + 1);
+
+    const uint8_t *d_refs = b->d_refs;
+    if (flags & CE_FLAG_XYB_ROUNDTRIP) {
+        // MetricConfig::xyb_roundtrip: every metric sees the roundtripped reference (session.rs:447-456)
+        if (!b->d_refs_rt) CE_HIP(ctx, hipMalloc(&b->d_refs_rt, b->img_bytes * b->max_refs + 16));
+        int rc = ce_launch_xyb_roundtrip(ctx, b->d_refs, b->d_refs_rt, (size_t)n_refs_used * b->w * b->h);
+        if (rc != CE_OK) return rc;
+        d_refs = b->d_refs_rt;
+    }
+    if (metric_mask & CE_METRIC_PSNR) {
+        int rc = ce_launch_psnr(b, d_refs, n_pairs);
+        if (rc != CE_OK) return rc;
+    }
+    if ((metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8) {
+        int rc = ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs);
+        if (rc != CE_OK) return rc;
+    }
+    if (metric_mask & (CE_METRIC_DSSIM | CE_METRIC_BUTTERAUGLI))
+        return fail(ctx, CE_ERR_BACKEND, "DSSIM / Butteraugli kernels are not built yet");
+    b->last_n_pairs = n_pairs;
+    b->last_mask = metric_mask;
+    return CE_OK;
+}
+
+int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
+{
+    if (!b || !out) return CE_ERR_INVALID_ARG;
+    ce_ctx *ctx = b->ctx;
+    if (n_pairs == 0 || n_pairs > b->max_pairs) return fail(ctx, CE_ERR_INVALID_ARG, "n_pairs out of range");
+    CE_HIP(ctx, hipMemcpyAsync(b->h_scores, b->d_scores, sizeof(ce_dev_scores) * n_pairs, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t mask = b->last_mask;
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        ce_scores s{};
+        s.status = CE_OK;
+        const ce_dev_scores &d = b->h_scores[i];
+        if (mask & CE_METRIC_PSNR) {
+            s.psnr = psnr_from_sse(d.sse, b->w, b->h);
+            s.valid |= CE_METRIC_PSNR;
+        }
+        if (mask & CE_METRIC_SSIMULACRA2) {
+            if (b->w < 8 || b->h < 8) {
+                s.status = CE_ERR_TOO_SMALL;
+            } else {
+                s.ssimulacra2 = d.ssimulacra2;
+                s.valid |= CE_METRIC_SSIMULACRA2;
+            }
+        }
+        out[i] = s;
+    }
+    return CE_OK;
+}
+
+int ce_batch_run(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags, float intensity_target,
+                 ce_scores *out)
+{
+    int rc = ce_batch_launch(b, n_pairs, metric_mask, flags, intensity_target);
+    if (rc != CE_OK) return rc;
+    return ce_batch_collect(b, n_pairs, out);
+}
+
+// ---- single pair / mixed batch ----------------------------------------------------------------
+
+static int shape_batch(ce_ctx *ctx, uint32_t w, uint32_t h, uint32_t need_pairs, ce_batch **out)
+{
+    auto key = std::make_pair(w, h);
+    auto it = ctx->shape_pool.find(key);
+    if (it != ctx->shape_pool.end() && it->second->max_pairs >= need_pairs) {
+        *out = it->second;
+        return CE_OK;
+    }
+    if (it != ctx->shape_pool.end()) {
+        ce_batch_destroy(it->second);
+        ctx->shape_pool.erase(it);
+    }
+    ce_batch *b = nullptr;
+    int rc = ce_batch_create(ctx, w, h, need_pairs, need_pairs, &b);
+    if (rc != CE_OK) return rc;
+    ctx->shape_pool[key] = b;
+    *out = b;
+    return CE_OK;
+}
+
+int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t metric_mask, uint32_t flags,
+                  float intensity_target, ce_scores *out)
+{
+    if (!ctx || (!pairs && n) || (!out && n)) return CE_ERR_INVALID_ARG;
+    // bucket by shape (Kodak mixes 768x512 and 512x768); invalid items never reach the device
+    std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> buckets;
+    for (size_t i = 0; i < n; i++) {
+        out[i] = ce_scores{};
+        const ce_pair_desc &d = pairs[i];
+        int rc = (!d.reference || !d.test || d.width == 0 || d.height == 0)
+                     ? CE_ERR_INVALID_ARG
+                     : validate_pair(ctx, d.reference_len, d.test_len, d.width, d.height);
+        if (rc != CE_OK) {
+            out[i].status = rc;
+            continue;
+        }
+        buckets[{d.width, d.height}].push_back(i);
+    }
+    for (auto &kv : buckets) {
+        const std::vector<size_t> &idx = kv.second;
+        ce_batch *b = nullptr;
+        int rc = shape_batch(ctx, kv.first.first, kv.first.second, (uint32_t)idx.size(), &b);
+        if (rc != CE_OK) return rc;
+        // identical reference pointers share one device slot (the quality sweep of one source image)
+        std::map<const uint8_t *, uint32_t> ref_slot;
+        for (size_t k = 0; k < idx.size(); k++) {
+            const ce_pair_desc &d = pairs[idx[k]];
+            auto it = ref_slot.find(d.reference);
+            uint32_t slot;
+            if (it == ref_slot.end()) {
+                slot = (uint32_t)ref_slot.size();
+                ref_slot[d.reference] = slot;
+                rc = ce_batch_set_reference(b, slot, d.reference, d.reference_len);
+                if (rc != CE_OK) return rc;
+            } else {
+                slot = it->second;
+            }
+            rc = ce_batch_set_test(b, (uint32_t)k, slot, d.test, d.test_len);
+            if (rc != CE_OK) return rc;
+        }
+        std::vector<ce_scores> tmp(idx.size());
+        rc = ce_batch_run(b, (uint32_t)idx.size(), metric_mask, flags, intensity_target, tmp.data());
+        if (rc != CE_OK) return rc;
+        for (size_t k = 0; k < idx.size(); k++) out[idx[k]] = tmp[k];
+    }
+    return CE_OK;
+}
+
+int ce_eval_pair(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test, size_t test_len,
+                 uint32_t width, uint32_t height, uint32_t metric_mask, uint32_t flags, float intensity_target,
+                 ce_scores *out)
+{
+    if (!ctx || !out || !reference || !test) return CE_ERR_INVALID_ARG;
+    ce_pair_desc d{reference, reference_len, test, test_len, width, height};
+    int rc = ce_eval_batch(ctx, 1, &d, metric_mask, flags, intensity_target, out);
+    if (rc != CE_OK) return rc;
+    return out->status;
+}
+
+static int leaf(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test, size_t test_len,
+                size_t width, size_t height, uint32_t metric, float intensity, double *out)
+{
+    if (!ctx || !out) return CE_ERR_INVALID_ARG;
+    ce_scores s{};
+    int rc = ce_eval_pair(ctx, reference, reference_len, test, test_len, (uint32_t)width, (uint32_t)height, metric, 0,
+                          intensity, &s);
+    if (rc != CE_OK) return rc;
+    *out = metric == CE_METRIC_PSNR          ? s.psnr
+           : metric == CE_METRIC_SSIMULACRA2 ? s.ssimulacra2
+           : metric == CE_METRIC_DSSIM       ? s.dssim
+                                             : s.butteraugli;
+    return CE_OK;
+}
+
+int ce_calculate_psnr(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                      size_t test_len, size_t width, size_t height, double *out)
+{
+    return leaf(ctx, reference, reference_len, test, test_len, width, height, CE_METRIC_PSNR, 0.f, out);
+}
+
+int ce_calculate_ssimulacra2(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                             size_t test_len, size_t width, size_t height, double *out)
+{
+    return leaf(ctx, reference, reference_len, test, test_len, width, height, CE_METRIC_SSIMULACRA2, 0.f, out);
+}
+
+int ce_calculate_dssim(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                       size_t test_len, size_t width, size_t height, double *out)
+{
+    return leaf(ctx, reference, reference_len, test, test_len, width, height, CE_METRIC_DSSIM, 0.f, out);
+}
+
+int ce_calculate_butteraugli(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                             size_t test_len, size_t width, size_t height, float intensity_target, double *out)
+{
+    return leaf(ctx, reference, reference_len, test, test_len, width, height, CE_METRIC_BUTTERAUGLI, intensity_target,
+                out);
+}
+
+int ce_xyb_roundtrip(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height, uint8_t *out)
+{
+    if (!ctx || !rgb || !out) return CE_ERR_INVALID_ARG;
+    if (rgb_len != width * height * 3)
+        return fail(ctx, CE_ERR_BAD_LENGTH, "Buffer size mismatch");  // xyb.rs:227
+    if (rgb_len == 0) return CE_OK;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    CE_HIP(ctx, hipMalloc(&d_in, rgb_len));
+    if (hipMalloc(&d_out, rgb_len) != hipSuccess) {
+        hipFree(d_in);
+        return fail(ctx, CE_ERR_BACKEND, "hipMalloc failed");
+    }
+    int rc = CE_OK;
+    if (hipMemcpy(d_in, rgb, rgb_len, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "H2D failed");
+    if (rc == CE_OK) rc = ce_launch_xyb_roundtrip(ctx, d_in, d_out, width * height);
+    if (rc == CE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "sync failed");
+    if (rc == CE_OK && hipMemcpy(out, d_out, rgb_len, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(ctx, CE_ERR_BACKEND, "D2H failed");
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+}
+
+int ce_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height,
+                           float *rgba_out)
+{
+    (void)rgb; (void)rgb_len; (void)width; (void)height; (void)rgba_out;
+    return fail(ctx, CE_ERR_BACKEND, "rgb8_to_dssim_image: not built yet");
+}
+
+// ---- reference handle -------------------------------------------------------------------------
+
+struct ce_ref {
+    ce_ctx *ctx;
+    ce_batch *batch;
+    uint32_t flags;
+};
+
+int ce_ref_create(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, uint32_t width, uint32_t height,
+                  uint32_t flags, ce_ref **out)
+{
+    if (!ctx || !reference || !out) return CE_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (reference_len != (size_t)width * height * 3)
+        return fail(ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " +
+                                                 std::to_string((size_t)width * height * 3) + " bytes, got " +
+                                                 std::to_string(reference_len));
+    ce_batch *b = nullptr;
+    int rc = ce_batch_create(ctx, width, height, 1, 1, &b);
+    if (rc != CE_OK) return rc;
+    rc = ce_batch_set_reference(b, 0, reference, reference_len);
+    if (rc != CE_OK) {
+        ce_batch_destroy(b);
+        return rc;
+    }
+    *out = new ce_ref{ctx, b, flags};
+    return CE_OK;
+}
+
+int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t metric_mask, float intensity_target,
+                   ce_scores *out)
+{
+    if (!ref || !test || !out) return CE_ERR_INVALID_ARG;
+    ce_batch *b = ref->batch;
+    if (test_len != b->img_bytes)
+        return fail(ref->ctx, CE_ERR_DIM_MISMATCH, "Dimension mismatch: reference " + std::to_string(b->img_bytes) +
+                                                        " bytes, test " + std::to_string(test_len) + " bytes");
+    int rc = ce_batch_set_test(b, 0, 0, test, test_len);
+    if (rc != CE_OK) return rc;
+    rc = ce_batch_run(b, 1, metric_mask, ref->flags, intensity_target, out);
+    if (rc != CE_OK) return rc;
+    return out->status;
+}
+
+void ce_ref_destroy(ce_ref *ref)
+{
+    if (!ref) return;
+    ce_batch_destroy(ref->batch);
+    delete ref;
+}
+
+// ---- measurement hooks ----------------------------------------------------------------------
+
+int ce_prof_enable(ce_ctx *ctx, int on)
+{
+    if (!ctx) return CE_ERR_INVALID_ARG;
+    prof_drain(ctx);
+    ctx->prof = on != 0;
+    return CE_OK;
+}
+
+int ce_prof_reset(ce_ctx *ctx)
+{
+    if (!ctx) return CE_ERR_INVALID_ARG;
+    prof_drain(ctx);
+    ctx->stats.clear();
+    return CE_OK;
+}
+
+int ce_prof_count(ce_ctx *ctx)
+{
+    if (!ctx) return 0;
+    prof_drain(ctx);
+    return (int)ctx->stats.size();
+}
+
+int ce_prof_get(ce_ctx *ctx, int index, const char **name, uint64_t *launches, double *total_ms)
+{
+    if (!ctx || index < 0 || index >= (int)ctx->stats.size()) return CE_ERR_INVALID_ARG;
+    prof_drain(ctx);
+    if (name) *name = ctx->stats[index].name.c_str();
+    if (launches) *launches = ctx->stats[index].launches;
+    if (total_ms) *total_ms = ctx->stats[index].total_ms;
+    return CE_OK;
+}
+
+int ce_timer_start(ce_ctx *ctx)
+{
+    if (!ctx) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return CE_OK;
+}
+
+int ce_timer_stop(ce_ctx *ctx, double *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    CE_HIP(ctx, hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    CE_HIP(ctx, hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    *elapsed_ms = ms;
+    return CE_OK;
+}
+
+// ---- test hooks -------------------------------------------------------------------------------
+
+int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float *out, size_t out_floats,
+                          uint32_t *w_out, uint32_t *h_out)
+{
+    if (!b || !out || !b->ssim2_ready || scale < 0 || scale >= b->n_scales) return CE_ERR_INVALID_ARG;
+    ce_ctx *ctx = b->ctx;
+    const ce_scale_dims &d = b->sd[scale];
+    const int nplanes = which == 4 ? CE_SSIM2_STREAMS : 3;
+    if (out_floats < (size_t)nplanes * d.w * d.h) return CE_ERR_INVALID_ARG;
+    const uint32_t ref_slot = b->h_pair_ref[0], test_slot = b->max_refs;
+    const float *src = nullptr;
+    // d_xyb and d_hbuf hold only the LAST level processed; the caller asks for that level
+    switch (which) {
+        case 0: src = b->d_lin[scale] + (size_t)ref_slot * 3 * d.plane; break;
+        case 1: src = b->d_lin[scale] + (size_t)test_slot * 3 * d.plane; break;
+        case 2: src = b->d_xyb + (size_t)ref_slot * 3 * d.plane; break;
+        case 3: src = b->d_xyb + (size_t)test_slot * 3 * d.plane; break;
+        case 4:
+            if (channel < 0 || channel > 2) return CE_ERR_INVALID_ARG;
+            src = b->d_hbuf + (size_t)channel * CE_SSIM2_STREAMS * d.plane;
+            break;
+        default: return CE_ERR_INVALID_ARG;
+    }
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < nplanes; p++)
+        CE_HIP(ctx, hipMemcpy2D(out + (size_t)p * d.w * d.h, (size_t)d.w * sizeof(float), src + (size_t)p * d.plane,
+                                (size_t)d.pitch * sizeof(float), (size_t)d.w * sizeof(float), d.h,
+                                hipMemcpyDeviceToHost));
+    if (w_out) *w_out = d.w;
+    if (h_out) *h_out = d.h;
+    return CE_OK;
+}
+
+int ce_debug_ssim2_limit_scales(ce_batch *b, int max_scales)
+{
+    if (!b || max_scales < 1 || max_scales > CE_MAX_SCALES) return CE_ERR_INVALID_ARG;
+    b->debug_max_scales = max_scales;
+    return CE_OK;
+}
+
+int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg, int *n_scales)
+{
+    if (!b || !avg || !b->ssim2_ready || pair_index >= b->max_pairs) return CE_ERR_INVALID_ARG;
+    ce_ctx *ctx = b->ctx;
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CE_HIP(ctx, hipMemcpy(avg, b->d_avg + (size_t)pair_index * CE_MAX_SCALES * 18, sizeof(double) * CE_MAX_SCALES * 18,
+                          hipMemcpyDeviceToHost));
+    if (n_scales) *n_scales = b->n_scales;
+    return CE_OK;
+}
+
+}  // extern "C"

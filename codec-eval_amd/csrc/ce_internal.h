@@ -1,0 +1,123 @@
+// Internal declarations shared by the host runtime (ce_api.cpp) and the gfx950 kernels.
+// Nothing here is part of the ABI; the ABI is include/ce_metrics.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ce_metrics.h"
+
+#define CE_MAX_SCALES 6      // SSIMULACRA2 pyramid depth
+#define CE_SSIM2_STREAMS 5   // blur(a), blur(b), blur(a*a), blur(b*b), blur(a*b)
+
+struct ce_scale_dims {
+    uint32_t w, h, pitch;  // pitch in floats, multiple of 32 (128-byte rows)
+    size_t plane;          // pitch * h
+};
+
+// per-pair device results; PSNR leaves the device as the exact integer SSE and is
+// finished on the host with the host libm (bit-identical to the reference's f64 log10).
+struct ce_dev_scores {
+    double dssim;
+    double ssimulacra2;
+    double butteraugli;
+    unsigned long long sse;
+};
+
+struct ce_kernel_stat {
+    std::string name;
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct ce_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+
+    // device constant tables (built on the host at context creation)
+    float *d_lut_ssim2 = nullptr;  // sRGB->linear, f64 formula rounded to f32 (SSIMULACRA2 front end)
+    float *d_lut_powf = nullptr;   // sRGB->linear via f32 powf(2.4) (dssim.rs:78-85, xyb.rs:60-66)
+    float *d_xyb_thresh = nullptr; // linear->sRGB u8 decision thresholds (xyb.rs:86-88)
+
+    // profiling
+    bool prof = false;
+    std::vector<ce_kernel_stat> stats;
+    struct pending { int stat; hipEvent_t e0, e1; };
+    std::vector<pending> pend;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    // scratch batches for the single-pair / mixed-shape entry points, keyed by shape
+    std::map<std::pair<uint32_t, uint32_t>, ce_batch *> shape_pool;
+};
+
+struct ce_batch {
+    ce_ctx *ctx = nullptr;
+    uint32_t w = 0, h = 0, max_refs = 0, max_pairs = 0;
+    size_t img_bytes = 0;  // w*h*3
+
+    uint8_t *d_refs = nullptr;     // [max_refs][h][w][3]
+    uint8_t *d_refs_rt = nullptr;  // XYB-roundtripped references (lazily allocated)
+    uint8_t *d_tests = nullptr;    // [max_pairs][h][w][3]
+    uint32_t *d_pair_ref = nullptr;
+    std::vector<uint32_t> h_pair_ref;
+    bool pair_ref_dirty = true;
+    uint8_t *h_stage = nullptr;  // pinned staging, one image
+
+    // SSIMULACRA2 working set.  Image slots: [0, max_refs) references, then tests.
+    int n_scales = 0;
+    ce_scale_dims sd[CE_MAX_SCALES];
+    float *d_lin[CE_MAX_SCALES] = {};  // [slots][3][plane_s] linear RGB pyramid
+    float *d_xyb = nullptr;            // [slots][3][plane_0]  (reused per scale)
+    float *d_hbuf = nullptr;           // [pairs][3][5][plane_0] row-blurred streams
+    double *d_partials = nullptr;      // [pairs][scales][3][max_blocks][6]
+    uint32_t max_vblocks = 0;
+    double *d_avg = nullptr;           // [pairs][6][3][6]
+    ce_dev_scores *d_scores = nullptr;
+    ce_dev_scores *h_scores = nullptr;  // pinned
+    bool ssim2_ready = false;
+    int debug_max_scales = CE_MAX_SCALES;  // test hook: stop the pyramid early
+
+    uint32_t last_n_pairs = 0;
+    uint32_t last_mask = 0;
+};
+
+#define CE_HIP(ctx_, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (ctx_)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return CE_ERR_BACKEND;                                                                 \
+        }                                                                                          \
+    } while (0)
+
+// profiling hooks around a launch (ce_api.cpp)
+int ce_prof_begin(ce_ctx *ctx, const char *name);
+void ce_prof_end(ce_ctx *ctx, int token);
+
+#define CE_LAUNCH(ctx_, name_, kern_, grid_, block_, shmem_, ...)                                  \
+    do {                                                                                           \
+        int tok__ = (ctx_)->prof ? ce_prof_begin((ctx_), name_) : -1;                              \
+        hipLaunchKernelGGL(kern_, grid_, block_, shmem_, (ctx_)->stream, __VA_ARGS__);             \
+        if (tok__ >= 0) ce_prof_end((ctx_), tok__);                                                \
+    } while (0)
+
+// ---- kernel launchers (one .hip file per metric) ---------------------------------------
+int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);
+int ce_ssim2_prepare(ce_batch *b);
+int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);
+int ce_launch_xyb_roundtrip(ce_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, size_t n_pixels);
+
+// host-side constant builders (ce_tables.cpp)
+void ce_build_srgb_lut_f64(float lut[256]);
+void ce_build_srgb_lut_powf(float lut[256]);
+void ce_ssim2_recursive_gaussian(float mul_in[3], float mul_prev[3]);
+bool ce_build_xyb_srgb_thresholds(float thresh[256]);

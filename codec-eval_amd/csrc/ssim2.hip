@@ -1,0 +1,441 @@
+// SSIMULACRA2 on gfx950 — replaces fast_ssim2::compute_ssimulacra2 behind
+// /root/reference/src/metrics/ssimulacra2.rs:96 and GpuSsim2::compute
+// (crates/codec-iter/src/gpu.rs:83-109).
+//
+// Pipeline per pyramid level (all pairs of the batch in one launch each):
+//   linear RGB (level 0: sRGB u8 through a 256-entry LDS table; level s>0: 2x2 box of level s-1)
+//   -> positive XYB planes
+//   -> row pass of the sigma=1.5 recursive Gaussian over the five streams a, b, a*a, b*b, a*b
+//   -> column pass of the same filter fused with the SSIM / edge-difference maps and their
+//      mean / 4-norm pooling (nothing but per-block partial sums is written)
+//   -> fixed-order reduction, 108-weight polynomial and remap to the score.
+//
+// The blur is the f32 second-order recursion of the libjxl lineage, executed with the same
+// operation order as the CPU restatement (oracle/ssimulacra2.c), so every plane is
+// bit-identical to it; the filter's poles sit on the unit circle and its f32 round-off is
+// NOT negligible at the score level (DESIGN.md "Why the recursive form is kept").
+// Build with -ffp-contract=off: every fused multiply-add below is explicit.
+#include <algorithm>
+
+#include "ce_internal.h"
+
+namespace {
+
+struct rg_consts {
+    float mul_in[3];
+    float mul_prev[3];
+};
+
+constexpr int kRowsPerBlock = 64;
+constexpr int kColsPerBlock = 64;
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, uint32_t max_refs)
+{
+    return z < n_refs_used ? z : max_refs + (z - n_refs_used);
+}
+
+// ---- level 0: sRGB u8 (interleaved) -> linear f32 planes -------------------------------
+__global__ __launch_bounds__(256) void k_ssim2_linear_u8(const uint8_t *__restrict__ refs,
+                                                         const uint8_t *__restrict__ tests,
+                                                         const float *__restrict__ lut, float *__restrict__ lin,
+                                                         uint32_t w, uint32_t h, uint32_t pitch, size_t plane,
+                                                         size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t z = blockIdx.z;
+    const uint32_t slot = slot_of(z, n_refs_used, max_refs);
+    const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
+    float *dst = lin + (size_t)slot * 3 * plane;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const uint8_t *px = src + ((size_t)y * w + x) * 3;
+    const size_t o = (size_t)y * pitch + x;
+    dst[o] = s_lut[px[0]];
+    dst[plane + o] = s_lut[px[1]];
+    dst[2 * plane + o] = s_lut[px[2]];
+}
+
+// ---- level s -> s+1: 2x2 box average of linear RGB, edge-clamped, ceil sizes -------------
+__global__ __launch_bounds__(256) void k_ssim2_downscale(const float *__restrict__ in, float *__restrict__ out,
+                                                         uint32_t iw, uint32_t ih, uint32_t ipitch, size_t iplane,
+                                                         uint32_t ow, uint32_t oh, uint32_t opitch, size_t oplane,
+                                                         uint32_t n_refs_used, uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs);
+    const uint32_t c = blockIdx.z % 3;
+    const uint32_t ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const float *ip = in + ((size_t)slot * 3 + c) * iplane;
+    const uint32_t x0 = ox * 2, y0 = oy * 2;
+    const uint32_t x1 = min(x0 + 1, iw - 1), y1 = min(y0 + 1, ih - 1);
+    float sum = 0.0f;
+    sum += ip[(size_t)y0 * ipitch + x0];
+    sum += ip[(size_t)y0 * ipitch + x1];
+    sum += ip[(size_t)y1 * ipitch + x0];
+    sum += ip[(size_t)y1 * ipitch + x1];
+    out[((size_t)slot * 3 + c) * oplane + (size_t)oy * opitch + ox] = sum * 0.25f;
+}
+
+// ---- linear RGB -> positive XYB -----------------------------------------------------------
+// cube root: bit-trick seed and two f64 Newton steps rounded once to f32 (the msun cbrtf
+// scheme); IEEE basic operations only, so host and device agree bit for bit.
+__device__ __forceinline__ float cbrt_f32(float x)
+{
+    uint32_t hx = __float_as_uint(x) & 0x7fffffffu;
+    if (hx == 0) return x;
+    float t;
+    if (hx < 0x00800000u) {
+        t = __uint_as_float(0x4b800000u) * x;
+        t = __uint_as_float((__float_as_uint(t) & 0x7fffffffu) / 3 + 642849266u);
+    } else {
+        t = __uint_as_float(hx / 3 + 709958130u);
+    }
+    double T = (double)t, r;
+    const double xd = (double)x;
+    r = T * T * T;
+    T = T * (xd + xd + r) / (xd + r + r);
+    r = T * T * T;
+    T = T * (xd + xd + r) / (xd + r + r);
+    return (float)T;
+}
+
+#define K_M00 0.30f
+#define K_M02 0.078f
+#define K_M01 (1.0f - K_M02 - K_M00)
+#define K_M10 0.23f
+#define K_M12 0.078f
+#define K_M11 (1.0f - K_M12 - K_M10)
+#define K_M20 0.24342268924547819f
+#define K_M21 0.20476744424496821f
+#define K_M22 (1.0f - K_M20 - K_M21)
+#define K_B0 0.0037930732552754493f
+
+__device__ __forceinline__ void linear_to_xyb_positive(float r, float g, float b, float cbrt_bias, float &X, float &Y,
+                                                       float &B)
+{
+    const float m01 = K_M01, m11 = K_M11, m22 = K_M22;
+    float m0 = __builtin_fmaf(K_M00, r, __builtin_fmaf(m01, g, __builtin_fmaf(K_M02, b, K_B0)));
+    float m1 = __builtin_fmaf(K_M10, r, __builtin_fmaf(m11, g, __builtin_fmaf(K_M12, b, K_B0)));
+    float m2 = __builtin_fmaf(K_M20, r, __builtin_fmaf(K_M21, g, __builtin_fmaf(m22, b, K_B0)));
+    m0 = cbrt_f32(m0 < 0.0f ? 0.0f : m0) - cbrt_bias;
+    m1 = cbrt_f32(m1 < 0.0f ? 0.0f : m1) - cbrt_bias;
+    m2 = cbrt_f32(m2 < 0.0f ? 0.0f : m2) - cbrt_bias;
+    X = 0.5f * (m0 - m1);
+    Y = 0.5f * (m0 + m1);
+    B = m2;
+    B = (B - Y) + 0.55f;
+    X = __builtin_fmaf(X, 14.0f, 0.42f);
+    Y = Y + 0.01f;
+}
+
+__global__ __launch_bounds__(256) void k_ssim2_xyb(const float *__restrict__ lin, float *__restrict__ xyb, uint32_t w,
+                                                   uint32_t h, uint32_t pitch, size_t plane, uint32_t n_refs_used,
+                                                   uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t o = (size_t)slot * 3 * plane + (size_t)y * pitch + x;
+    const float cbrt_bias = cbrt_f32(K_B0);
+    float X, Y, B;
+    linear_to_xyb_positive(lin[o], lin[o + plane], lin[o + 2 * plane], cbrt_bias, X, Y, B);
+    xyb[o] = X;
+    xyb[o + plane] = Y;
+    xyb[o + 2 * plane] = B;
+}
+
+// one step of the three second-order sections for one stream; returns the filter output
+__device__ __forceinline__ float rg_step(float sum, float (&prev)[3], float (&prev2)[3], const rg_consts &rg)
+{
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v = sum * rg.mul_in[k];
+        v = __builtin_fmaf(-1.0f, prev2[k], v);
+        prev2[k] = prev[k];
+        v = __builtin_fmaf(rg.mul_prev[k], prev[k], v);
+        prev[k] = v;
+        o[k] = v;
+    }
+    return o[0] + o[1] + o[2];
+}
+
+// ---- row pass: one thread per (row, channel, pair), all five streams -------------------
+// Input step i consumes in[i] (right tap, n+N-1) and in[i-10] (left tap, n-N-1) and emits
+// output n = i-4.  Four steps per iteration so loads and stores are 16-byte.
+__global__ __launch_bounds__(kRowsPerBlock) void k_ssim2_hblur(const float *__restrict__ xyb,
+                                                               const uint32_t *__restrict__ pair_ref,
+                                                               float *__restrict__ hbuf, uint32_t w, uint32_t h,
+                                                               uint32_t pitch, size_t plane, uint32_t max_refs,
+                                                               rg_consts rg)
+{
+    const uint32_t y = blockIdx.x * kRowsPerBlock + threadIdx.x;
+    if (y >= h) return;
+    const uint32_t c = blockIdx.y, p = blockIdx.z;
+    const float *a = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + (size_t)y * pitch;
+    const float *b = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + (size_t)y * pitch;
+    float *o = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + (size_t)y * pitch;
+
+    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3];
+#pragma unroll
+    for (int s = 0; s < CE_SSIM2_STREAMS; s++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) prev[s][k] = prev2[s][k] = 0.0f;
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 am1 = zero4, am2 = zero4, am3 = zero4, bm1 = zero4, bm2 = zero4, bm3 = zero4;
+    const uint32_t nj = (w + 4 + 3) / 4;
+    for (uint32_t j = 0; j < nj; j++) {
+        const uint32_t i0 = 4 * j;
+        float4 a0 = zero4, b0 = zero4;
+        if (i0 < w) {
+            a0 = *reinterpret_cast<const float4 *>(a + i0);
+            b0 = *reinterpret_cast<const float4 *>(b + i0);
+            if (i0 + 1 >= w) a0.y = b0.y = 0.0f;
+            if (i0 + 2 >= w) a0.z = b0.z = 0.0f;
+            if (i0 + 3 >= w) a0.w = b0.w = 0.0f;
+        }
+        const float ra[4] = {a0.x, a0.y, a0.z, a0.w}, rb[4] = {b0.x, b0.y, b0.z, b0.w};
+        const float la[4] = {am3.z, am3.w, am2.x, am2.y}, lb[4] = {bm3.z, bm3.w, bm2.x, bm2.y};
+        float out[CE_SSIM2_STREAMS][4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            out[0][e] = rg_step(la[e] + ra[e], prev[0], prev2[0], rg);
+            out[1][e] = rg_step(lb[e] + rb[e], prev[1], prev2[1], rg);
+            out[2][e] = rg_step(la[e] * la[e] + ra[e] * ra[e], prev[2], prev2[2], rg);
+            out[3][e] = rg_step(lb[e] * lb[e] + rb[e] * rb[e], prev[3], prev2[3], rg);
+            out[4][e] = rg_step(la[e] * lb[e] + ra[e] * rb[e], prev[4], prev2[4], rg);
+        }
+        if (j >= 1) {
+#pragma unroll
+            for (int s = 0; s < CE_SSIM2_STREAMS; s++)
+                *reinterpret_cast<float4 *>(o + (size_t)s * plane + (i0 - 4)) =
+                    make_float4(out[s][0], out[s][1], out[s][2], out[s][3]);
+        }
+        am3 = am2; am2 = am1; am1 = a0;
+        bm3 = bm2; bm2 = bm1; bm1 = b0;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- column pass + SSIM/edge maps + pooling: one thread per (column, channel, pair) ----
+__global__ __launch_bounds__(kColsPerBlock) void k_ssim2_vblur_ssim(const float *__restrict__ hbuf,
+                                                                    const float *__restrict__ xyb,
+                                                                    const uint32_t *__restrict__ pair_ref,
+                                                                    double *__restrict__ partials, uint32_t w,
+                                                                    uint32_t h, uint32_t pitch, size_t plane,
+                                                                    uint32_t max_refs, uint32_t scale,
+                                                                    uint32_t max_vblocks, rg_consts rg)
+{
+    const uint32_t xr = blockIdx.x * kColsPerBlock + threadIdx.x;
+    const bool active = xr < w;
+    const uint32_t x = active ? xr : w - 1;
+    const uint32_t c = blockIdx.y, p = blockIdx.z;
+    const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + x;
+    const float *xa = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + x;
+    const float *xb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + x;
+
+    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3], ring[10][CE_SSIM2_STREAMS];
+#pragma unroll
+    for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) prev[s][k] = prev2[s][k] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 10; e++) ring[e][s] = 0.0f;
+    }
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const float C2 = 0.0009f;
+    const uint32_t steps = h + 4;
+    for (uint32_t i0 = 0; i0 < steps; i0 += 10) {
+#pragma unroll
+        for (int e = 0; e < 10; e++) {
+            const uint32_t i = i0 + e;
+            if (i < steps) {
+                float v[CE_SSIM2_STREAMS];
+#pragma unroll
+                for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
+                    const float right = i < h ? hb[(size_t)s * plane + (size_t)i * pitch] : 0.0f;
+                    const float left = ring[e][s];
+                    ring[e][s] = right;
+                    v[s] = rg_step(left + right, prev[s], prev2[s], rg);
+                }
+                if (i >= 4) {
+                    const uint32_t n = i - 4;
+                    const float img1 = xa[(size_t)n * pitch], img2 = xb[(size_t)n * pitch];
+                    const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
+                    const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+                    const float mu_diff = mu1 - mu2;
+                    const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
+                    const float num_s = __builtin_fmaf(2.0f, s12 - mu12, C2);
+                    const float denom_s = (s11 - mu11) + (s22 - mu22) + C2;
+                    double d = 1.0 - (double)((num_m * num_s) / denom_s);
+                    if (!(d > 0.0)) d = 0.0;
+                    acc[0] += d;
+                    const double d2 = d * d;
+                    acc[1] += d2 * d2;
+                    const double d1 = (1.0 + (double)fabsf(img2 - mu2)) / (1.0 + (double)fabsf(img1 - mu1)) - 1.0;
+                    const double artifact = d1 > 0.0 ? d1 : 0.0;
+                    const double detail = -d1 > 0.0 ? -d1 : 0.0;
+                    acc[2] += artifact;
+                    const double a2 = artifact * artifact;
+                    acc[3] += a2 * a2;
+                    acc[4] += detail;
+                    const double l2 = detail * detail;
+                    acc[5] += l2 * l2;
+                }
+            }
+        }
+    }
+    double *dst = partials + ((((size_t)p * CE_MAX_SCALES + scale) * 3 + c) * max_vblocks + blockIdx.x) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const double s = wave_sum(active ? acc[q] : 0.0);
+        if (threadIdx.x == 0) dst[q] = s;
+    }
+}
+
+__constant__ double c_weight[108] = {
+    0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0, 1.1041726426657346, 0.00066284834129271, 0.00015231632783718752,
+    0.0, 0.0016406437456599754, 0.0, 1.8422455520539298, 11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0, 1.8787594979546387, 10.94906990605142, 0.0,
+    0.0007289346991508072, 0.9677937080626833, 0.0, 0.00014003424285435884, 0.9981766977854967, 0.00031949755934435053, 0.0004550992113792063, 0.0, 0.0, 0.0013648766163243398, 0.0, 0.0,
+    0.0, 0.0, 0.0, 7.466890328078848, 0.0, 17.445833984131262, 0.0006235601634041466, 0.0, 0.0, 6.683678146179332, 0.00037724407979611296, 1.027889937768264,
+    225.20515300849274, 0.0, 0.0, 19.213238186143016, 0.0011401524586618361, 0.001237755635509985, 176.39317598450694, 0.0, 0.0, 24.43300999870476, 0.28520802612117757, 0.0004485436923833408,
+    0.0, 0.0, 0.0, 34.77906344483772, 44.835625328877896, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0,
+    0.0, 0.0008680556573291698, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0005313191874358747, 0.0, 0.00016533814161379112, 0.0, 0.0,
+    0.0, 0.0, 0.0, 0.0004179171803251336, 0.0017290828234722833, 0.0, 0.0020827005846636437, 0.0, 0.0, 8.826982764996862, 23.19243343998926, 0.0,
+    95.1080498811086, 0.9863978034400682, 0.9834382792465353, 0.0012286405048278493, 171.2667255897307, 0.9807858872435379, 0.0, 0.0, 0.0, 0.0005130064588990679, 0.0, 0.00010854057858411537,
+};
+
+struct scale_geom {
+    uint32_t npix[CE_MAX_SCALES];
+    uint32_t nblk[CE_MAX_SCALES];
+};
+
+// ---- fixed-order reduction of the block partials, then Msssim::score -------------------
+__global__ __launch_bounds__(128) void k_ssim2_finalize(const double *__restrict__ partials, double *__restrict__ avg,
+                                                        ce_dev_scores *__restrict__ scores, uint32_t n_scales,
+                                                        uint32_t max_vblocks, scale_geom g)
+{
+    __shared__ double s_avg[CE_MAX_SCALES * 3 * 6];
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    if (t < n_scales * 18) {
+        const uint32_t s = t / 18, c = (t / 6) % 3, q = t % 6;
+        const double *src = partials + ((((size_t)p * CE_MAX_SCALES + s) * 3 + c) * max_vblocks) * 6 + q;
+        double sum = 0.0;
+        for (uint32_t k = 0; k < g.nblk[s]; k++) sum += src[(size_t)k * 6];
+        const double one_per_pixels = 1.0 / (double)g.npix[s];
+        double v = one_per_pixels * sum;
+        if (q & 1) v = sqrt(sqrt(v));
+        s_avg[t] = v;
+        avg[(size_t)p * CE_MAX_SCALES * 18 + t] = v;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double ssim = 0.0;
+        int i = 0;
+        for (uint32_t c = 0; c < 3; c++)
+            for (uint32_t s = 0; s < n_scales; s++) {
+                const double *a = s_avg + (s * 3 + c) * 6;
+                for (int n = 0; n < 2; n++) {
+                    ssim = fma(c_weight[i++], fabs(a[0 + n]), ssim);
+                    ssim = fma(c_weight[i++], fabs(a[2 + n]), ssim);
+                    ssim = fma(c_weight[i++], fabs(a[4 + n]), ssim);
+                }
+            }
+        ssim *= 0.9562382616834844;
+        ssim = fma(6.248496625763138e-5 * ssim * ssim, ssim,
+                   fma(2.326765642916932, ssim, -0.020884521182843837 * ssim * ssim));
+        if (ssim > 0.0)
+            ssim = fma(pow(ssim, 0.6276336467831387), -10.0, 100.0);
+        else
+            ssim = 100.0;
+        scores[p].ssimulacra2 = ssim;
+    }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------
+
+int ce_ssim2_prepare(ce_batch *b)
+{
+    if (b->ssim2_ready) return CE_OK;
+    ce_ctx *ctx = b->ctx;
+    uint32_t w = b->w, h = b->h;
+    int ns = 0;
+    for (int s = 0; s < CE_MAX_SCALES; s++) {
+        if (w < 8 || h < 8) break;
+        ce_scale_dims &d = b->sd[s];
+        d.w = w;
+        d.h = h;
+        d.pitch = (w + 31u) & ~31u;
+        d.plane = (size_t)d.pitch * h;
+        ns++;
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+    }
+    b->n_scales = ns;
+    if (ns == 0) return CE_OK;
+    const size_t slots = (size_t)b->max_refs + b->max_pairs;
+    for (int s = 0; s < ns; s++)
+        CE_HIP(ctx, hipMalloc(&b->d_lin[s], slots * 3 * b->sd[s].plane * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->d_xyb, slots * 3 * b->sd[0].plane * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->d_hbuf, (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[0].plane * sizeof(float)));
+    b->max_vblocks = (b->sd[0].w + kColsPerBlock - 1) / kColsPerBlock;
+    CE_HIP(ctx, hipMalloc(&b->d_partials, (size_t)b->max_pairs * CE_MAX_SCALES * 3 * b->max_vblocks * 6 * sizeof(double)));
+    CE_HIP(ctx, hipMalloc(&b->d_avg, (size_t)b->max_pairs * CE_MAX_SCALES * 18 * sizeof(double)));
+    b->ssim2_ready = true;
+    return CE_OK;
+}
+
+int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs)
+{
+    ce_ctx *ctx = b->ctx;
+    int rc = ce_ssim2_prepare(b);
+    if (rc != CE_OK) return rc;
+    rg_consts rg;
+    ce_ssim2_recursive_gaussian(rg.mul_in, rg.mul_prev);
+    const uint32_t n_slots = n_refs_used + n_pairs;
+    scale_geom g{};
+    const int levels = std::min(b->n_scales, b->debug_max_scales);
+    for (int s = 0; s < levels; s++) {
+        const ce_scale_dims &d = b->sd[s];
+        const dim3 pix_grid((d.w + 63) / 64, (d.h + 3) / 4, n_slots);
+        if (s == 0) {
+            CE_LAUNCH(ctx, "ssim2_linear_u8", k_ssim2_linear_u8, pix_grid, dim3(256), 0, d_refs, b->d_tests,
+                      ctx->d_lut_ssim2, b->d_lin[0], d.w, d.h, d.pitch, d.plane, b->img_bytes, n_refs_used,
+                      b->max_refs);
+        } else {
+            const ce_scale_dims &pd = b->sd[s - 1];
+            CE_LAUNCH(ctx, "ssim2_downscale", k_ssim2_downscale, dim3(pix_grid.x, pix_grid.y, n_slots * 3), dim3(256),
+                      0, b->d_lin[s - 1], b->d_lin[s], pd.w, pd.h, pd.pitch, pd.plane, d.w, d.h, d.pitch, d.plane,
+                      n_refs_used, b->max_refs);
+        }
+        CE_LAUNCH(ctx, "ssim2_xyb", k_ssim2_xyb, pix_grid, dim3(256), 0, b->d_lin[s], b->d_xyb, d.w, d.h, d.pitch,
+                  d.plane, n_refs_used, b->max_refs);
+        CE_LAUNCH(ctx, "ssim2_hblur", k_ssim2_hblur, dim3((d.h + kRowsPerBlock - 1) / kRowsPerBlock, 3, n_pairs),
+                  dim3(kRowsPerBlock), 0, b->d_xyb, b->d_pair_ref, b->d_hbuf, d.w, d.h, d.pitch, d.plane, b->max_refs,
+                  rg);
+        const uint32_t nblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
+        CE_LAUNCH(ctx, "ssim2_vblur_ssim", k_ssim2_vblur_ssim, dim3(nblk, 3, n_pairs), dim3(kColsPerBlock), 0,
+                  b->d_hbuf, b->d_xyb, b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs,
+                  (uint32_t)s, b->max_vblocks, rg);
+        g.npix[s] = d.w * d.h;
+        g.nblk[s] = nblk;
+    }
+    CE_LAUNCH(ctx, "ssim2_finalize", k_ssim2_finalize, dim3(n_pairs), dim3(128), 0, b->d_partials, b->d_avg,
+              b->d_scores, (uint32_t)levels, b->max_vblocks, g);
+    CE_HIP(ctx, hipGetLastError());
+    return CE_OK;
+}

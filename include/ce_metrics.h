@@ -1,0 +1,193 @@
+/*
+ * ce_metrics.h — C ABI of libce_metrics_hip.so, the MI355X (gfx950) backend for the
+ * perceptual-metric hot path of imazen/codec-eval.
+ *
+ * Every entry point replaces one reference interface; the citation after each
+ * declaration is the Rust item (path relative to the reference checkout) whose
+ * FFI binding would call it.  Conventions (reference: SURVEY.md §8b):
+ *
+ *   pixels     tightly packed interleaved RGB8, row-major, no stride
+ *              (src/metrics/ssimulacra2.rs:41,72; src/eval/session.rs:98-117)
+ *   ownership  every pointer is borrowed for the duration of the call only; the
+ *              library copies what it needs and owns all device memory
+ *   errors     integer status, never abort/panic; ce_last_error() gives the text.
+ *              CE_ERR_DIM_MISMATCH  <-> Error::DimensionMismatch  (src/error.rs:31-38)
+ *              CE_ERR_BAD_LENGTH    <-> Error::MetricCalculation{"Invalid image size"}
+ *                                       (src/metrics/ssimulacra2.rs:73-82)
+ *              CE_ERR_TOO_SMALL     <-> Error::MetricCalculation from the metric crate
+ *                                       for images under 8x8 (src/eval/helpers.rs:89)
+ *              CE_ERR_BACKEND       <-> Error::MetricCalculation{reason: backend text}
+ *              PSNR in the reference asserts (src/metrics/mod.rs:313-314); here it
+ *              returns the code and the Rust shim re-raises the panic.
+ *   results    double, as MetricResult's Option<f64> (src/metrics/mod.rs:140-149)
+ *   threading  one in-flight call per context (GpuSsim2::compute takes &mut self,
+ *              crates/codec-iter/src/gpu.rs:83); any number of contexts per device;
+ *              no global mutable state.
+ *   no torch / no C++ types in any signature.
+ */
+#ifndef CE_METRICS_H
+#define CE_METRICS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ce_ctx ce_ctx;     /* device + stream + scratch pool       */
+typedef struct ce_batch ce_batch; /* HBM-resident grid of (ref, test) pairs of one shape */
+typedef struct ce_ref ce_ref;     /* one reference image held on device   */
+
+enum ce_status {
+    CE_OK = 0,
+    CE_ERR_DIM_MISMATCH = 1,
+    CE_ERR_BAD_LENGTH = 2,
+    CE_ERR_TOO_SMALL = 3,
+    CE_ERR_BACKEND = 4,
+    CE_ERR_INVALID_ARG = 5
+};
+
+/* MetricConfig (src/metrics/mod.rs:46-63) as a bit mask */
+enum ce_metric {
+    CE_METRIC_DSSIM = 1u << 0,
+    CE_METRIC_SSIMULACRA2 = 1u << 1,
+    CE_METRIC_BUTTERAUGLI = 1u << 2,
+    CE_METRIC_PSNR = 1u << 3
+};
+enum ce_flag {
+    CE_FLAG_XYB_ROUNDTRIP = 1u << 0 /* MetricConfig::xyb_roundtrip: reference side only (session.rs:447-456) */
+};
+
+#define CE_DEFAULT_INTENSITY_TARGET 80.0f /* src/metrics/butteraugli.rs:94 */
+
+/* MetricResult (src/metrics/mod.rs:140-149): a score is meaningful iff its bit is
+ * set in `valid`; `status` is the ce_status of this pair. */
+typedef struct ce_scores {
+    double dssim;
+    double ssimulacra2;
+    double butteraugli;
+    double psnr;
+    uint32_t valid;
+    int32_t status;
+} ce_scores;
+
+/* one work item of the (image x codec x quality) grid */
+typedef struct ce_pair_desc {
+    const uint8_t *reference;
+    size_t reference_len;
+    const uint8_t *test;
+    size_t test_len;
+    uint32_t width;
+    uint32_t height;
+} ce_pair_desc;
+
+/* ---- library / device -------------------------------------------------------- */
+const char *ce_version(void);
+int ce_device_count(void); /* number of visible HIP devices; <0 on runtime failure */
+
+/* GpuSsim2::new (crates/codec-iter/src/gpu.rs:40-80) without the fixed-shape limit:
+ * scratch is keyed by (w,h) and grows on demand. */
+int ce_ctx_create(int device, ce_ctx **out);
+/* same, launching on a caller-owned hipStream_t (passed as void*); NULL = own stream */
+int ce_ctx_create_on_stream(int device, void *hip_stream, ce_ctx **out);
+/* Drop for GpuSsim2 (gpu.rs:118-133): synchronises the stream, then frees */
+void ce_ctx_destroy(ce_ctx *ctx);
+int ce_ctx_synchronize(ce_ctx *ctx);
+void *ce_ctx_stream(ce_ctx *ctx); /* the hipStream_t kernels are launched on */
+const char *ce_last_error(const ce_ctx *ctx);
+
+/* ---- leaf metric calls: one per reference leaf function ------------------------ */
+/* calculate_psnr                       src/metrics/mod.rs:312 */
+int ce_calculate_psnr(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                      size_t test_len, size_t width, size_t height, double *out);
+/* calculate_ssimulacra2                src/metrics/ssimulacra2.rs:59 ; GpuSsim2::compute gpu.rs:83 */
+int ce_calculate_ssimulacra2(ce_ctx *ctx, const uint8_t *reference, size_t reference_len,
+                             const uint8_t *test, size_t test_len, size_t width, size_t height,
+                             double *out);
+/* rgb8_to_dssim_image x2 + calculate_dssim   src/metrics/dssim.rs:102,40 (session.rs:467-476) */
+int ce_calculate_dssim(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                       size_t test_len, size_t width, size_t height, double *out);
+/* calculate_butteraugli / _with_intensity    src/metrics/butteraugli.rs:45,99 */
+int ce_calculate_butteraugli(ce_ctx *ctx, const uint8_t *reference, size_t reference_len,
+                             const uint8_t *test, size_t test_len, size_t width, size_t height,
+                             float intensity_target, double *out);
+/* xyb_roundtrip                         src/metrics/xyb.rs:225 ; out has rgb_len bytes */
+int ce_xyb_roundtrip(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height,
+                     uint8_t *out);
+/* rgb8_to_dssim_image                   src/metrics/dssim.rs:102 ; out has 4*w*h floats (a = 1.0) */
+int ce_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height,
+                           float *rgba_out);
+
+/* ---- dispatcher --------------------------------------------------------------- */
+/* EvalSession::calculate_metrics        src/eval/session.rs:437-497
+ * evaluate_single                       src/eval/helpers.rs:105-173 */
+int ce_eval_pair(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, const uint8_t *test,
+                 size_t test_len, uint32_t width, uint32_t height, uint32_t metric_mask, uint32_t flags,
+                 float intensity_target, ce_scores *out);
+
+/* The (codec x quality) double loop of EvalSession::evaluate_image (session.rs:375-376)
+ * and images.par_iter() of crates/codec-compare/src/full_comparison.rs:319-328, as one
+ * call: n independent pairs, any mix of shapes (bucketed by shape internally).
+ * Per-pair failures are reported in out[i].status; the return value is CE_OK unless the
+ * call itself could not run. */
+int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t metric_mask, uint32_t flags,
+                  float intensity_target, ce_scores *out);
+
+/* ---- HBM-resident grid (what bench.py times; inputs already on device) ---------- */
+/* One shape, up to max_refs reference images and max_pairs (reference, test) items. */
+int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_refs, uint32_t max_pairs,
+                    ce_batch **out);
+void ce_batch_destroy(ce_batch *b);
+/* host -> device copies (pinned staging inside) */
+int ce_batch_set_reference(ce_batch *b, uint32_t ref_index, const uint8_t *rgb, size_t len);
+int ce_batch_set_test(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const uint8_t *rgb, size_t len);
+/* device pointers of the packed u8 slabs ([max_refs][h][w][3], [max_pairs][h][w][3]) so a caller that
+ * already has pixels in HBM (e.g. a GPU decoder) can write them in place */
+void *ce_batch_reference_slab(ce_batch *b);
+void *ce_batch_test_slab(ce_batch *b);
+int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index);
+/* run the hot path over pairs [0, n_pairs); blocks until scores are on the host */
+int ce_batch_run(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags, float intensity_target,
+                 ce_scores *out);
+/* same, without the final synchronise + D2H (for back-to-back timed steps); scores are
+ * fetched by ce_batch_collect */
+int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags,
+                    float intensity_target);
+int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out);
+
+/* ---- reference handle: Ssimulacra2Reference::{new,compare} ------------------------
+ * crates/codec-iter/src/eval.rs:138-149,83-89; crates/codec-compare/src/brute_force_sweep.rs:197-201,256 */
+int ce_ref_create(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, uint32_t width, uint32_t height,
+                  uint32_t flags, ce_ref **out);
+int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t metric_mask,
+                   float intensity_target, ce_scores *out);
+void ce_ref_destroy(ce_ref *ref);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------ */
+/* Bracket every kernel launch with HIP events on the context's stream and accumulate
+ * per-kernel time.  Off by default (events perturb back-to-back launches). */
+int ce_prof_enable(ce_ctx *ctx, int on);
+int ce_prof_reset(ce_ctx *ctx);
+/* number of distinct kernels seen; then per index: name, launches, total ms */
+int ce_prof_count(ce_ctx *ctx);
+int ce_prof_get(ce_ctx *ctx, int index, const char **name, uint64_t *launches, double *total_ms);
+/* plain HIP-event stopwatch on the context's stream */
+int ce_timer_start(ce_ctx *ctx);
+int ce_timer_stop(ce_ctx *ctx, double *elapsed_ms);
+
+/* ---- test hooks: stage outputs of the SSIMULACRA2 pipeline (plane-level parity) --- */
+/* Copies the device planes of pair 0 of the last ce_batch_run at `scale` to host.
+ * which: 0 = linear RGB ref, 1 = linear RGB test, 2 = XYB ref, 3 = XYB test (3*h*w floats,
+ * planar), 4 = the 5 row-blurred planes of channel `channel` (5*h*w floats). */
+int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float *out, size_t out_floats,
+                          uint32_t *w_out, uint32_t *h_out);
+/* stop the pyramid after max_scales levels (so the level-0 XYB / row-blur planes survive the run) */
+int ce_debug_ssim2_limit_scales(ce_batch *b, int max_scales);
+/* avg[scale][c][6] of pair `pair_index` from the last run (ssim l1,l4, artifact l1,l4, detail l1,l4) */
+int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg /* [6][3][6] */, int *n_scales);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

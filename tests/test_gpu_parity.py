@@ -1,0 +1,247 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bars (BASELINE.json north_star): PSNR and the XYB roundtrip bit-exact;
+SSIMULACRA2 / DSSIM / Butteraugli within 1e-4 relative.
+
+The synthetic inputs mirror the reference's own tests (src/metrics/*.rs #[cfg(test)]).
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # north_star: "within 1e-4 relative"
+
+
+def rel_close(got, want, rel=REL_TOL, floor=1.0):
+    """|got - want| <= rel * max(|want|, floor).  floor=1 for scores whose natural scale is O(1..100)."""
+    return abs(got - want) <= rel * max(abs(want), floor)
+
+
+def ramp(w, h):
+    # src/metrics/ssimulacra2.rs:155  (0..w*h*3).map(|i| (i % 256) as u8)
+    return (np.arange(w * h * 3) % 256).astype(np.uint8)
+
+
+def helper_pattern(w, h, pattern):
+    # src/eval/helpers.rs:327-335 (wrapping `as u8` casts)
+    i = np.arange(w * h)
+    base = (i + pattern) % 256
+    return np.stack([base, base + 50, base + 100], 1).astype(np.uint8).reshape(h, w, 3)
+
+
+# ---------------------------------------------------------------- PSNR (bit-exact) ----------
+
+
+def test_psnr_reference_cases(gpu_ctx, oracle):
+    # src/metrics/mod.rs:368-383
+    same = np.full(100 * 100 * 3, 128, np.uint8)
+    assert math.isinf(gpu_ctx.calculate_psnr(same, same, 100, 100))
+    r, t = np.full(30000, 100, np.uint8), np.full(30000, 110, np.uint8)
+    got = gpu_ctx.calculate_psnr(r, t, 100, 100)
+    assert 28.0 < got < 29.0
+    assert got == oracle.psnr(r, t, 100, 100)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (7, 7), (64, 64), (100, 100), (101, 77), (768, 512), (512, 768), (1920, 1080)])
+def test_psnr_bit_exact(gpu_ctx, oracle, w, h):
+    rng = np.random.default_rng(w * 10007 + h)
+    r = rng.integers(0, 256, w * h * 3, dtype=np.uint8)
+    t = np.clip(r.astype(np.int16) + rng.integers(-9, 10, r.size), 0, 255).astype(np.uint8)
+    assert gpu_ctx.calculate_psnr(r, t, w, h) == oracle.psnr(r, t, w, h)
+    # worst case: every sample differs by 255
+    z, f = np.zeros(w * h * 3, np.uint8), np.full(w * h * 3, 255, np.uint8)
+    assert gpu_ctx.calculate_psnr(z, f, w, h) == oracle.psnr(z, f, w, h) == 0.0
+
+
+def test_psnr_errors(gpu_ctx, ce):
+    a, b = np.zeros(50 * 50 * 3, np.uint8), np.zeros(100 * 100 * 3, np.uint8)
+    with pytest.raises(ce.DimensionMismatch):  # mod.rs:313 asserts; here an error code
+        gpu_ctx.calculate_psnr(a, b, 100, 100)
+    with pytest.raises(ce.MetricCalculation):  # mod.rs:314
+        gpu_ctx.calculate_psnr(a, a, 100, 100)
+
+
+# ---------------------------------------------------------- XYB roundtrip (bit-exact) -------
+
+
+def test_xyb_roundtrip_reference_cases(gpu_ctx, oracle):
+    # src/metrics/xyb.rs:259-272
+    rgb = (np.arange(64 * 64 * 3) % 256).astype(np.uint8)
+    out = gpu_ctx.xyb_roundtrip(rgb, 64, 64)
+    assert out.size == rgb.size
+    rgb2 = ((np.arange(32 * 32 * 3) * 7) % 256).astype(np.uint8)
+    a, b = gpu_ctx.xyb_roundtrip(rgb2, 32, 32), gpu_ctx.xyb_roundtrip(rgb2, 32, 32)
+    assert np.array_equal(a, b)
+    assert np.array_equal(out, oracle.xyb_roundtrip(rgb, 64, 64))
+
+
+def test_xyb_roundtrip_all_colours_bit_exact(gpu_ctx, oracle):
+    """Every sRGB colour (2^24 pixels): the function is pointwise, so this is exhaustive.
+    Also re-derives the known-answer table of src/metrics/xyb.rs:15-24 from the device output."""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    rgb = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], 1).astype(np.uint8)
+    got = gpu_ctx.xyb_roundtrip(rgb, 4096, 4096).reshape(-1, 3)
+    want = oracle.xyb_roundtrip(rgb, 4096, 4096).reshape(-1, 3)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, f"{bad.size} colours differ, first: in={rgb[bad[0]]} gpu={got[bad[0]]} oracle={want[bad[0]]}"
+    diff = np.abs(got.astype(np.int16) - rgb.astype(np.int16)).max(axis=1)
+    n = float(diff.size)
+    assert abs((diff == 0).sum() / n * 100 - 15.7) < 0.05
+    assert abs((diff <= 1).sum() / n * 100 - 71.3) < 0.05
+    assert abs((diff <= 2).sum() / n * 100 - 84.7) < 0.05
+    assert abs((diff <= 5).sum() / n * 100 - 95.8) < 0.05
+    assert abs((diff <= 10).sum() / n * 100 - 99.3) < 0.05
+    assert diff.max() == 26
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 1), (3, 1), (5, 7), (101, 77)])
+def test_xyb_roundtrip_ragged(gpu_ctx, oracle, w, h):
+    rng = np.random.default_rng(w + 31 * h)
+    rgb = rng.integers(0, 256, w * h * 3, dtype=np.uint8)
+    assert np.array_equal(gpu_ctx.xyb_roundtrip(rgb, w, h), oracle.xyb_roundtrip(rgb, w, h))
+
+
+# ------------------------------------------------------------------- SSIMULACRA2 -------------
+
+
+def test_ssim2_reference_cases(gpu_ctx, oracle, ce):
+    # src/metrics/ssimulacra2.rs:153-182
+    d = ramp(100, 100)
+    assert gpu_ctx.calculate_ssimulacra2(d, d, 100, 100) > 99.0
+    r, t = np.full(30000, 100, np.uint8), np.full(30000, 200, np.uint8)
+    got = gpu_ctx.calculate_ssimulacra2(r, t, 100, 100)
+    assert got < 80.0
+    assert rel_close(got, oracle.ssimulacra2(r, t, 100, 100, 1))
+    small, large = np.full(50 * 50 * 3, 128, np.uint8), np.full(100 * 100 * 3, 128, np.uint8)
+    with pytest.raises(ce.CodecEvalError):
+        gpu_ctx.calculate_ssimulacra2(small, large, 100, 100)
+    with pytest.raises(ce.MetricCalculation):  # ssimulacra2.rs:72-82
+        gpu_ctx.calculate_ssimulacra2(small, small, 100, 100)
+    with pytest.raises(ce.MetricCalculation):  # below 8x8
+        gpu_ctx.calculate_ssimulacra2(small[: 7 * 7 * 3], small[: 7 * 7 * 3], 7, 7)
+
+
+def test_ssim2_planes_bit_exact(gpu_ctx, oracle, ce, workloads):
+    """Stage outputs of level 0 against the oracle's building blocks: every plane identical."""
+    w, h = 200, 136
+    ref = workloads.make_reference(w, h, 11)
+    test = workloads.distort(ref, 70)
+    b = ce.Batch(gpu_ctx, w, h, 1, 1)
+    b.debug_limit_scales(1)
+    b.set_reference(0, ref)
+    b.set_test(0, 0, test)
+    b.run(1, ce.MetricConfig.ssimulacra2_only())
+    lin_r, lin_t = oracle.ssim2_linear_planar(ref, w, h), oracle.ssim2_linear_planar(test, w, h)
+    assert np.array_equal(b.debug_planes(0, 0), lin_r)
+    assert np.array_equal(b.debug_planes(0, 1), lin_t)
+    xyb_r, xyb_t = oracle.ssim2_xyb_positive(lin_r), oracle.ssim2_xyb_positive(lin_t)
+    assert np.array_equal(b.debug_planes(0, 2), xyb_r)
+    assert np.array_equal(b.debug_planes(0, 3), xyb_t)
+    b.close()
+
+
+SHAPES = [(8, 8), (9, 15), (16, 8), (33, 17), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512), (512, 768)]
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_ssim2_parity_shapes(gpu_ctx, oracle, ce, workloads, w, h):
+    ref = workloads.make_reference(w, h, 100 + w)
+    for q in (30, 75, 95):
+        test = workloads.distort(ref, q)
+        want, want_avg = oracle.ssimulacra2_detail(ref, test, w, h, 1)
+        b = ce.Batch(gpu_ctx, w, h, 1, 1)
+        b.set_reference(0, ref)
+        b.set_test(0, 0, test)
+        s = b.run(1, ce.MetricConfig.ssimulacra2_only())[0]
+        got_avg = b.debug_averages(0)
+        b.close()
+        assert s.status == 0 and s.valid & ce.METRIC_SSIMULACRA2
+        assert got_avg.shape == want_avg.shape
+        # the planes are bit-identical, so the pooled averages differ only by f64 summation order
+        np.testing.assert_allclose(got_avg, want_avg, rtol=1e-10, atol=1e-15)
+        assert rel_close(s.ssimulacra2, want), (w, h, q, s.ssimulacra2, want)
+
+
+def test_ssim2_edge_content(gpu_ctx, oracle, workloads):
+    w, h = 96, 80
+    flat = workloads.make_reference(w, h, 5, "flat")
+    noise = workloads.make_reference(w, h, 6, "highfreq")
+    for a, b in ((flat, flat), (noise, noise), (flat, noise), (noise, flat), (np.zeros_like(flat), np.full_like(flat, 255))):
+        got = gpu_ctx.calculate_ssimulacra2(a, b, w, h)
+        assert rel_close(got, oracle.ssimulacra2(a, b, w, h, 1)), got
+    assert gpu_ctx.calculate_ssimulacra2(noise, noise, w, h) == 100.0
+
+
+def test_helpers_mirror(gpu_ctx, ce):
+    # src/eval/helpers.rs:337-383 (DSSIM / Butteraugli halves are added with those kernels)
+    img, shifted = helper_pattern(64, 64, 0), helper_pattern(64, 64, 50)
+    res = ce.evaluate_single(gpu_ctx, img, img, ce.MetricConfig(ssimulacra2=True, psnr=True))
+    assert res.ssimulacra2 > 99.0 and math.isinf(res.psnr)
+    with pytest.raises(ce.DimensionMismatch):
+        ce.evaluate_single(gpu_ctx, img, helper_pattern(32, 32, 0), ce.MetricConfig.ssimulacra2_only())
+    ce.assert_quality(gpu_ctx, img, img, 90.0, None)
+    with pytest.raises(ce.QualityBelowThreshold):
+        ce.assert_quality(gpu_ctx, img, shifted, 99.0, None)
+
+
+# --------------------------------------------------------- batch / grid semantics --------------
+
+
+def test_batch_grid_matches_single_calls(gpu_ctx, oracle, ce, workloads):
+    """One resident grid (2 refs x 3 qualities, shared reference slots) == six single calls == oracle."""
+    w, h = 128, 96
+    refs = [workloads.make_reference(w, h, 40 + i) for i in range(2)]
+    b = ce.Batch(gpu_ctx, w, h, 2, 6)
+    tests = []
+    for i, r in enumerate(refs):
+        b.set_reference(i, r)
+        for k, q in enumerate((50, 75, 90)):
+            t = workloads.distort(r, q)
+            tests.append((i, t))
+            b.set_test(i * 3 + k, i, t)
+    cfg = ce.MetricConfig(ssimulacra2=True, psnr=True)
+    out = b.run(6, cfg)
+    for (i, t), s in zip(tests, out):
+        assert s.psnr == oracle.psnr(refs[i], t, w, h)
+        assert rel_close(s.ssimulacra2, oracle.ssimulacra2(refs[i], t, w, h, 1))
+        single = gpu_ctx.calculate_metrics(refs[i], t, w, h, cfg)
+        assert single.ssimulacra2 == s.ssimulacra2 and single.psnr == s.psnr  # batching changes nothing
+    b.close()
+
+
+def test_eval_batch_mixed_shapes_and_errors(gpu_ctx, oracle, ce, workloads):
+    a = workloads.make_reference(96, 64, 1)
+    b_ = workloads.make_reference(64, 96, 2)
+    ta, tb = workloads.distort(a, 60), workloads.distort(b_, 60)
+    pairs = [(a, ta, 96, 64), (b_, tb, 64, 96), (a, tb[:10], 96, 64), (a, ta, 95, 64)]
+    out = gpu_ctx.eval_batch(pairs, ce.MetricConfig(ssimulacra2=True, psnr=True))
+    assert out[0].status == 0 and out[1].status == 0
+    assert out[2].status == ce.CE_ERR_DIM_MISMATCH and out[3].status == ce.CE_ERR_BAD_LENGTH
+    assert out[0].psnr == oracle.psnr(a, ta, 96, 64) and out[1].psnr == oracle.psnr(b_, tb, 64, 96)
+    assert rel_close(out[1].ssimulacra2, oracle.ssimulacra2(b_, tb, 64, 96, 1))
+
+
+def test_xyb_flag_applies_to_reference_only(gpu_ctx, oracle, ce, workloads):
+    # session.rs:447-456: the reference is roundtripped, the test image is not
+    w, h = 80, 72
+    ref = workloads.make_reference(w, h, 3)
+    test = workloads.distort(ref, 80)
+    got = gpu_ctx.calculate_metrics(ref, test, w, h, ce.MetricConfig(ssimulacra2=True, psnr=True, xyb_roundtrip=True))
+    rt = oracle.xyb_roundtrip(ref, w, h)
+    assert got.psnr == oracle.psnr(rt, test, w, h)
+    assert rel_close(got.ssimulacra2, oracle.ssimulacra2(rt, test, w, h, 1))
+
+
+def test_reference_handle(gpu_ctx, oracle, ce, workloads):
+    # Ssimulacra2Reference::{new, compare}, crates/codec-iter/src/eval.rs:138-149,83-89
+    w, h = 112, 88
+    ref = workloads.make_reference(w, h, 9)
+    hd = ce.ReferenceHandle(gpu_ctx, ref, w, h)
+    for q in (40, 70, 92):
+        t = workloads.distort(ref, q)
+        assert rel_close(hd.compare(t).ssimulacra2, oracle.ssimulacra2(ref, t, w, h, 1))
+    with pytest.raises(ce.DimensionMismatch):
+        hd.compare(ref[:10])
+    hd.close()
