@@ -374,16 +374,20 @@ int ce_ssim2_prepare(ce_batch *b)
     ce_ctx *ctx = b->ctx;
     uint32_t w = b->w, h = b->h;
     int ns = 0;
+    // The lineage tests the size BEFORE halving (`if w < 8 || h < 8 {break}; if scale > 0
+    // {downscale}`), so a level smaller than 8 px exists whenever its parent was >= 8.
     for (int s = 0; s < CE_MAX_SCALES; s++) {
         if (w < 8 || h < 8) break;
+        if (s > 0) {
+            w = (w + 1) / 2;
+            h = (h + 1) / 2;
+        }
         ce_scale_dims &d = b->sd[s];
         d.w = w;
         d.h = h;
         d.pitch = (w + 31u) & ~31u;
         d.plane = (size_t)d.pitch * h;
         ns++;
-        w = (w + 1) / 2;
-        h = (h + 1) / 2;
     }
     b->n_scales = ns;
     if (ns == 0) return CE_OK;
