@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on the MI355X hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (N = 1): BASELINE.json configs[1] — "Kodak-24 x 3 quality levels, SSIMULACRA2 only, one
+MI355X (768x512 buffers)": 24 synthetic references in Kodak's shapes (18 of 768x512, 6 of 512x768)
+x q in {75, 85, 95} = 72 (reference, distorted) pairs, 28.3 MP per step.  Inputs are uploaded once
+and are resident in HBM when the timed region starts.  A step = one pass of the hot path over the
+whole grid, scores returned to the host.
+
+N > 1: the grid shards by reference image with no data-path collective; every rank owns its own
+Kodak-24-shaped corpus (different seeds), i.e. per-GPU work is fixed => "scaling": "weak".
+torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of the time.
+
+Extra JSON objects: "roofline" (dominant kernel, HIP-event timed live) and "cpu_baseline"
+(the C oracle timed on this host's cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# SURVEY.md §8(d) algorithmic bytes, counting rules R1-R6
+SSIM2_BYTES_PER_PX0_TOTAL = 210.0  # whole metric, per scale-0 pixel of a pair
+SSIM2_PASS_BYTES_L0 = 66.0  # one blur pass at level 0: 60 B of blurred planes + 6 B of u8 input
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="6 references instead of 24 (smoke runs)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+
+    import codec_eval_amd as ce
+    import importlib
+
+    wl = importlib.import_module("codec-eval_amd.workloads")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- build this rank's shard of the grid (synthetic, seeded) --------------------------------
+    qualities = (75, 85, 95)  # codec-iter "quick" preset, crates/codec-iter/src/main.rs:197
+    n_land, n_port = (5, 1) if args.quick else (wl.KODAK_LANDSCAPE, wl.KODAK_PORTRAIT)
+    grids = wl.kodak_like(qualities, n_land, n_port, seed0=1000 + 100 * rank)
+    cfg = ce.MetricConfig.ssimulacra2_only()
+
+    ctx = ce.Context(local_rank)
+    batches = []
+    for g in grids:
+        b = ce.Batch(ctx, g.width, g.height, len(g.references), len(g.pairs))
+        for i, r in enumerate(g.references):
+            b.set_reference(i, r)
+        for k, (ri, t) in enumerate(g.pairs):
+            b.set_test(k, ri, t)
+        batches.append((g, b))
+    pairs_per_step = sum(len(g.pairs) for g in grids)
+    mp_per_step = sum(g.megapixels for g in grids)
+
+    def step():
+        for g, b in batches:
+            b.launch(len(g.pairs), cfg)
+        return [b.collect(len(g.pairs)) for g, b in batches]
+
+    for _ in range(args.warmup):
+        step()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        scores = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_mp = mp_per_step * args.steps * world
+    value = total_mp / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline: per-kernel HIP-event timing of the same steps (separate pass: events perturb) ----
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        for _ in range(args.steps):
+            step()
+        ctx.prof_enable(False)
+        kernels = ctx.prof_stats()
+        total_ms = sum(ms for _, ms in kernels.values())
+        name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
+        px0 = sum(len(g.pairs) * g.width * g.height for g in grids)  # scale-0 pixels per step
+        n_launch_per_step = launches / args.steps
+        avg_s = ms / launches * 1e-3
+        bytes_per_launch = SSIM2_PASS_BYTES_L0 * px0 / n_launch_per_step
+        achieved = bytes_per_launch / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(name)
+        roofline = {
+            "bound": "hbm",
+            "kernel": name,
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": round(avg_s * 1e3, 4),
+            "launches": launches,
+            "kernel_share_of_gpu_time": round(ms / total_ms, 3),
+            # the whole metric against the same peak: 210 B per scale-0 pixel
+            "pipeline_achieved": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 * args.steps / (total_ms * 1e-3) / 1e9, 1),
+            "pipeline_frac": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 * args.steps / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+        }
+
+    # ---- CPU baseline: the C oracle on this host's cores (rank 0, N = 1 only) -------------------
+    cpu_baseline = None
+    max_dev = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+
+        O.build()
+        items = [(g, ri, t) for g in grids for (ri, t) in g.pairs]
+
+        def one(it):
+            g, ri, t = it
+            return O.ssimulacra2(g.references[ri], t, g.width, g.height, 1)
+
+        n1 = min(len(items), 12)
+        t1 = time.perf_counter()
+        cpu_scores_1 = [one(it) for it in items[:n1]]
+        dt1 = time.perf_counter() - t1
+        mp1 = sum(g.width * g.height for g, _, _ in items[:n1]) / 1e6
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        tN = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL: item-level parallelism,
+            cpu_scores = list(ex.map(one, items))  # mirrors images.par_iter() (full_comparison.rs:319-328)
+        dtN = time.perf_counter() - tN
+        cpu_baseline = {
+            "value": round(mp_per_step / dtN, 3),
+            "unit": "MP/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": f"all {len(items)} pairs of the workload, once, {cores} threads over items "
+                      f"(C restatement of the metric; the Rust crates cannot be built offline)",
+            "value_1thread": round(mp1 / dt1, 3),
+            "sample_1thread": f"first {n1} pairs, 1 thread",
+        }
+        gpu_scores = [s.ssimulacra2 for sc in scores for s in sc]
+        max_dev = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(gpu_scores, cpu_scores))
+
+    if rank == 0:
+        line = {
+            "metric": "metric MP/s (SSIMULACRA2+DSSIM+Butteraugli) at 1/2/4/8 GPU; HBM-roofline %",
+            "value": round(value, 2),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: Kodak-24 x 3 quality levels (q75/85/95), SSIMULACRA2 only, "
+                            "768x512 x18 + 512x768 x6 buffers" + (" [--quick subset]" if args.quick else ""),
+                "pairs_per_gpu_step": pairs_per_step,
+                "megapixels_per_gpu_step": round(mp_per_step, 3),
+                "metrics": ["ssimulacra2"],
+                "sharding": "by reference image, one process + one HIP stream per GPU, no collective",
+                "inputs": "resident in HBM (uploaded before the timed region)",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "max_rel_dev_vs_oracle": max_dev,
+            "kernels_ms_per_step": {k: round(ms / args.steps, 4) for k, (n, ms) in sorted(kernels.items())},
+        }
+        print(json.dumps(line), flush=True)
+
+    for _, b in batches:
+        b.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

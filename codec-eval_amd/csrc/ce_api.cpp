@@ -639,15 +639,15 @@ int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float 
         case 3: src = b->d_xyb + (size_t)test_slot * 3 * d.plane; break;
         case 4:
             if (channel < 0 || channel > 2) return CE_ERR_INVALID_ARG;
-            src = b->d_hbuf + (size_t)channel * CE_SSIM2_STREAMS * d.plane;
+            src = b->d_hbuf + (size_t)channel * CE_SSIM2_STREAMS * d.hplane;
             break;
         default: return CE_ERR_INVALID_ARG;
     }
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t spl = which == 4 ? d.hplane : d.plane, spitch = which == 4 ? d.hpitch : d.pitch;
     for (int p = 0; p < nplanes; p++)
-        CE_HIP(ctx, hipMemcpy2D(out + (size_t)p * d.w * d.h, (size_t)d.w * sizeof(float), src + (size_t)p * d.plane,
-                                (size_t)d.pitch * sizeof(float), (size_t)d.w * sizeof(float), d.h,
-                                hipMemcpyDeviceToHost));
+        CE_HIP(ctx, hipMemcpy2D(out + (size_t)p * d.w * d.h, (size_t)d.w * sizeof(float), src + (size_t)p * spl,
+                                spitch * sizeof(float), (size_t)d.w * sizeof(float), d.h, hipMemcpyDeviceToHost));
     if (w_out) *w_out = d.w;
     if (h_out) *h_out = d.h;
     return CE_OK;

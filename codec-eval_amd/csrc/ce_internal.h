@@ -19,6 +19,8 @@
 struct ce_scale_dims {
     uint32_t w, h, pitch;  // pitch in floats, multiple of 32 (128-byte rows)
     size_t plane;          // pitch * h
+    uint32_t hpitch;       // row-blur planes: pitch padded to 32 * ceil((w + 4) / 32) floats,
+    size_t hplane;         //   rows padded to a multiple of 64 (branch-free row stores)
 };
 
 // per-pair device results; PSNR leaves the device as the exact integer SSE and is

@@ -222,6 +222,162 @@ __global__ __launch_bounds__(kRowsPerBlock) void k_ssim2_hblur(const float *__re
     }
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// queue (s_waitcnt vmcnt(0)), which would serialise the prefetch loads and the fire-and-forget
+// row stores with every barrier; here global memory is never exchanged between waves.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS reads/writes have landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// ---- row pass, LDS-staged line tiles ------------------------------------------------------
+// One block = 64 rows of one (pair, channel); wave s (0..4) runs stream s of
+// {a, b, a*a, b*b, a*b} with one row per lane, so every lane carries one 3-section filter
+// state.  Columns advance in chunks of 32.  The chunk's a/b values are fetched with coalesced
+// 16-byte row loads into registers two chunks ahead of the filter, then laid into LDS
+// column-major ([column][row], row stride 65 -> the per-lane row access is conflict-free).
+// The LDS input tile holds two 32-column halves: the chunk being filtered and the previous
+// one, which supplies the filter's left tap (10 columns back) for the first 10 steps, so all
+// LDS offsets are compile-time constants.  Outputs leave through a second LDS tile as
+// coalesced 16-byte row stores.
+#ifndef HB_ABLATE
+#define HB_ABLATE 0
+#endif
+constexpr int HB_ROWS = 64, HB_CW = 32, HB_LD = 65, HB_THREADS = 64 * CE_SSIM2_STREAMS;
+constexpr int HB_HALF = HB_CW * HB_LD;
+
+// Every stream is in[i] = P[i] * Q[i] with (P, Q) = (a, 1), (b, 1), (a, a), (b, b), (a, b).
+// One chunk = 32 filter steps: step e consumes the tile's column e (right tap) and the column
+// 10 back (left tap; for e < 10 that is in the previous chunk's half) and emits one output.
+template <bool PLAIN>
+__device__ __forceinline__ void hblur_chunk(const float *__restrict__ p_cur, const float *__restrict__ p_old,
+                                            const float *__restrict__ q_cur, const float *__restrict__ q_old,
+                                            float *__restrict__ so, float (&prev)[3], float (&prev2)[3],
+                                            const rg_consts &rg)
+{
+#pragma unroll
+    for (int e = 0; e < HB_CW; e++) {
+        const float pr = p_cur[e * HB_LD];
+        const float pl = e >= 10 ? p_cur[(e - 10) * HB_LD] : p_old[(HB_CW - 10 + e) * HB_LD];
+        float sum;
+        if (PLAIN) {
+            sum = pl + pr;
+        } else {
+            const float qr = q_cur[e * HB_LD];
+            const float ql = e >= 10 ? q_cur[(e - 10) * HB_LD] : q_old[(HB_CW - 10 + e) * HB_LD];
+            sum = pl * ql + pr * qr;
+        }
+        so[e * HB_LD] = rg_step(sum, prev, prev2, rg);
+    }
+}
+
+// Plane geometry (all planar f32 buffers): rows padded to a multiple of 64, pitch = 32 * ceil(w/32)
+// + 32, so every row load / store of a block is in bounds without a branch (branch-free memory
+// operations let the compiler count outstanding requests instead of draining them).
+//
+// Chunk c (0..N, N = ceil(w/32)) consumes input columns [32c-28, 32c+4) and emits output columns
+// [32c-32, 32c): the input tile is the one that sits 16 bytes off the 128-byte grid, so that the
+// (2.5x larger) output stores are whole aligned 128-byte lines.  Chunk 0 only primes the filter
+// (columns < 0 are the zero padding; its outputs n < 0 do not exist).
+// Wave s loads rows [32*(s&1), +32) of plane (s>>1) (waves 0-3) and stores its own stream's tile.
+template <int LEVEL>
+__global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *__restrict__ xyb,
+                                                                   const uint32_t *__restrict__ pair_ref,
+                                                                   float *__restrict__ hbuf, uint32_t w, uint32_t h,
+                                                                   uint32_t pitch, size_t plane, uint32_t max_refs,
+                                                                   rg_consts rg)
+{
+    __shared__ float s_in[2][2 * HB_HALF];  // [plane a|b][half][column][row]
+    __shared__ float s_out[CE_SSIM2_STREAMS * HB_HALF];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t s = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform stream index
+    const uint32_t y0 = blockIdx.x * HB_ROWS, c = blockIdx.y, p = blockIdx.z;
+    const float *ga = xyb + ((size_t)pair_ref[p] * 3 + c) * plane;
+    const float *gb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane;
+    const int n_chunks = (int)(pitch / HB_CW);  // N + 1
+    const uint32_t lr = lane >> 3, lq = lane & 7;  // row-in-group, float4-in-row of this lane's slots
+
+    // load slots m = 0..3: row 32*(s&1) + 8m + lr of plane s>>1, columns 32c-28+4*lq .. +3 of chunk c
+    const bool loader = s < 4;
+    const uint32_t lrow0 = (s & 1) * 32 + lr;
+    const float *src = ((s >> 1) & 1 ? gb : ga) + (size_t)(y0 + lrow0) * pitch;
+    float *sdst = &s_in[(s >> 1) & 1][(4 * lq) * HB_LD + lrow0];
+    // store slots m = 0..7: row 8m + lr of this wave's stream tile, columns 32(c-1)+4*lq .. +3
+    float *odst = hbuf + (((size_t)p * 3 + c) * CE_SSIM2_STREAMS + s) * plane + (size_t)(y0 + lr) * pitch + 4 * lq;
+    const float *osrc = &s_out[s * HB_HALF + (4 * lq) * HB_LD + lr];
+
+    float4 pf[2][4];  // two chunks in flight
+    auto load_chunk = [&](int k, float4 (&dst)[4]) {
+        if (loader) {
+            const int col = max(HB_CW * k - 28 + 4 * (int)lq, 0);  // clamped: always a readable address
+#pragma unroll
+            for (int m = 0; m < 4; m++) dst[m] = *reinterpret_cast<const float4 *>(src + (size_t)(8 * m) * pitch + col);
+        }
+    };
+    auto stash_chunk = [&](int k, const float4 (&v)[4]) {
+        if (loader) {
+            const int col = HB_CW * k - 28 + 4 * (int)lq;  // outside [0, w) the filter sees zeros
+            float *dst = sdst + (k & 1) * HB_HALF;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const bool rv = y0 + lrow0 + 8 * m < h && col >= 0;  // col is a multiple of 4: sign is per float4
+                dst[8 * m] = (rv && col < (int)w) ? v[m].x : 0.0f;
+                dst[8 * m + HB_LD] = (rv && col + 1 < (int)w) ? v[m].y : 0.0f;
+                dst[8 * m + 2 * HB_LD] = (rv && col + 2 < (int)w) ? v[m].z : 0.0f;
+                dst[8 * m + 3 * HB_LD] = (rv && col + 3 < (int)w) ? v[m].w : 0.0f;
+            }
+        }
+    };
+
+    // the half "before chunk 0" is all zero padding
+    for (uint32_t i = tid; i < 4 * HB_HALF; i += HB_THREADS) (&s_in[0][0])[i] = 0.0f;
+    load_chunk(0, pf[0]);
+    if (n_chunks > 1) load_chunk(1, pf[1]);
+    __syncthreads();
+    stash_chunk(0, pf[0]);
+    __syncthreads();
+
+    float prev[3] = {0.f, 0.f, 0.f}, prev2[3] = {0.f, 0.f, 0.f};
+    const float *sp = &s_in[(s == 1 || s == 3) ? 1 : 0][lane];
+    const float *sq = &s_in[(s == 2 || s == 0) ? 0 : 1][lane];  // a*a -> a, b*b and a*b -> b (unused when plain)
+    float *so = &s_out[s * HB_HALF + lane];
+
+    // While chunk k is filtered, chunk k+1 is in flight in `nxt`; chunk k+2 is requested into `cur`,
+    // whose previous content (chunk k) is already in LDS.
+    auto hblur_iter = [&](int k, float4 (&cur)[4], const float4 (&nxt)[4]) {
+        if (k + 2 < n_chunks) load_chunk(k + 2, cur);
+        const uint32_t oc = (k & 1) * HB_HALF, oo = HB_HALF - oc;
+        if (s < 2)
+            hblur_chunk<true>(sp + oc, sp + oo, sq + oc, sq + oo, so, prev, prev2, rg);
+        else
+            hblur_chunk<false>(sp + oc, sp + oo, sq + oc, sq + oo, so, prev, prev2, rg);
+        // the wave stores its own tile (whole 128-byte lines)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (k > 0) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const float4 v = make_float4(osrc[8 * m], osrc[8 * m + HB_LD], osrc[8 * m + 2 * HB_LD], osrc[8 * m + 3 * HB_LD]);
+#if HB_ABLATE != 1
+                *reinterpret_cast<float4 *>(odst + (size_t)(8 * m) * pitch + (size_t)(HB_CW * (k - 1))) = v;
+#else
+                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
+            }
+        }
+        lds_barrier();  // all waves are done reading the input halves
+        if (k + 1 < n_chunks) stash_chunk(k + 1, nxt);
+        lds_barrier();
+    };
+    for (int k = 0; k < n_chunks; k += 2) {
+        hblur_iter(k, pf[0], pf[1]);
+        if (k + 1 < n_chunks) hblur_iter(k + 1, pf[1], pf[0]);
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -235,6 +391,7 @@ __global__ __launch_bounds__(kColsPerBlock) void k_ssim2_vblur_ssim(const float 
                                                                     const uint32_t *__restrict__ pair_ref,
                                                                     double *__restrict__ partials, uint32_t w,
                                                                     uint32_t h, uint32_t pitch, size_t plane,
+                                                                    uint32_t hpitch, size_t hplane,
                                                                     uint32_t max_refs, uint32_t scale,
                                                                     uint32_t max_vblocks, rg_consts rg)
 {
@@ -242,7 +399,7 @@ __global__ __launch_bounds__(kColsPerBlock) void k_ssim2_vblur_ssim(const float 
     const bool active = xr < w;
     const uint32_t x = active ? xr : w - 1;
     const uint32_t c = blockIdx.y, p = blockIdx.z;
-    const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + x;
+    const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * hplane + x;
     const float *xa = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + x;
     const float *xb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + x;
 
@@ -265,7 +422,7 @@ __global__ __launch_bounds__(kColsPerBlock) void k_ssim2_vblur_ssim(const float 
                 float v[CE_SSIM2_STREAMS];
 #pragma unroll
                 for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
-                    const float right = i < h ? hb[(size_t)s * plane + (size_t)i * pitch] : 0.0f;
+                    const float right = i < h ? hb[(size_t)s * hplane + (size_t)i * hpitch] : 0.0f;
                     const float left = ring[e][s];
                     ring[e][s] = right;
                     v[s] = rg_step(left + right, prev[s], prev2[s], rg);
@@ -385,8 +542,10 @@ int ce_ssim2_prepare(ce_batch *b)
         ce_scale_dims &d = b->sd[s];
         d.w = w;
         d.h = h;
-        d.pitch = (w + 31u) & ~31u;
-        d.plane = (size_t)d.pitch * h;
+        d.pitch = ((w + HB_CW - 1) / HB_CW) * HB_CW + HB_CW;
+        d.plane = (size_t)d.pitch * (((size_t)h + HB_ROWS - 1) / HB_ROWS * HB_ROWS);
+        d.hpitch = d.pitch;
+        d.hplane = d.plane;
         ns++;
     }
     b->n_scales = ns;
@@ -395,7 +554,7 @@ int ce_ssim2_prepare(ce_batch *b)
     for (int s = 0; s < ns; s++)
         CE_HIP(ctx, hipMalloc(&b->d_lin[s], slots * 3 * b->sd[s].plane * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->d_xyb, slots * 3 * b->sd[0].plane * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->d_hbuf, (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[0].plane * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->d_hbuf, (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[0].hplane * sizeof(float)));
     b->max_vblocks = (b->sd[0].w + kColsPerBlock - 1) / kColsPerBlock;
     CE_HIP(ctx, hipMalloc(&b->d_partials, (size_t)b->max_pairs * CE_MAX_SCALES * 3 * b->max_vblocks * 6 * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->d_avg, (size_t)b->max_pairs * CE_MAX_SCALES * 18 * sizeof(double)));
@@ -411,6 +570,14 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     rg_consts rg;
     ce_ssim2_recursive_gaussian(rg.mul_in, rg.mul_prev);
     const uint32_t n_slots = n_refs_used + n_pairs;
+    static const char *const kHName[CE_MAX_SCALES] = {"ssim2_hblur_L0", "ssim2_hblur_L1", "ssim2_hblur_L2",
+                                                      "ssim2_hblur_L3", "ssim2_hblur_L4", "ssim2_hblur_L5"};
+    static const char *const kVName[CE_MAX_SCALES] = {"ssim2_vblur_ssim_L0", "ssim2_vblur_ssim_L1", "ssim2_vblur_ssim_L2",
+                                                      "ssim2_vblur_ssim_L3", "ssim2_vblur_ssim_L4", "ssim2_vblur_ssim_L5"};
+    using hblur_fn = void (*)(const float *, const uint32_t *, float *, uint32_t, uint32_t, uint32_t, size_t, uint32_t,
+                              rg_consts);
+    static const hblur_fn kHblur[CE_MAX_SCALES] = {k_ssim2_hblur_lds<0>, k_ssim2_hblur_lds<1>, k_ssim2_hblur_lds<2>,
+                                                   k_ssim2_hblur_lds<3>, k_ssim2_hblur_lds<4>, k_ssim2_hblur_lds<5>};
     scale_geom g{};
     const int levels = std::min(b->n_scales, b->debug_max_scales);
     for (int s = 0; s < levels; s++) {
@@ -428,12 +595,12 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         }
         CE_LAUNCH(ctx, "ssim2_xyb", k_ssim2_xyb, pix_grid, dim3(256), 0, b->d_lin[s], b->d_xyb, d.w, d.h, d.pitch,
                   d.plane, n_refs_used, b->max_refs);
-        CE_LAUNCH(ctx, "ssim2_hblur", k_ssim2_hblur, dim3((d.h + kRowsPerBlock - 1) / kRowsPerBlock, 3, n_pairs),
-                  dim3(kRowsPerBlock), 0, b->d_xyb, b->d_pair_ref, b->d_hbuf, d.w, d.h, d.pitch, d.plane, b->max_refs,
-                  rg);
+        CE_LAUNCH(ctx, kHName[s], kHblur[s], dim3((d.h + HB_ROWS - 1) / HB_ROWS, 3, n_pairs), dim3(HB_THREADS), 0,
+                  b->d_xyb, b->d_pair_ref, b->d_hbuf, d.w, d.h, d.pitch, d.plane, b->max_refs, rg);
         const uint32_t nblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
-        CE_LAUNCH(ctx, "ssim2_vblur_ssim", k_ssim2_vblur_ssim, dim3(nblk, 3, n_pairs), dim3(kColsPerBlock), 0,
-                  b->d_hbuf, b->d_xyb, b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs,
+        CE_LAUNCH(ctx, kVName[s], k_ssim2_vblur_ssim, dim3(nblk, 3, n_pairs), dim3(kColsPerBlock), 0,
+                  b->d_hbuf, b->d_xyb, b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, d.hpitch, d.hplane,
+                  b->max_refs,
                   (uint32_t)s, b->max_vblocks, rg);
         g.npix[s] = d.w * d.h;
         g.nblk[s] = nblk;
