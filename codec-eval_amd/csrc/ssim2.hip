@@ -462,6 +462,128 @@ __global__ __launch_bounds__(kColsPerBlock) void k_ssim2_vblur_ssim(const float 
     }
 }
 
+// ---- column pass v2: LDS-DMA ring, one wave per 64-column strip -----------------------------
+// Thread = column, all five streams (15 independent recurrences per lane).  The five row-blurred
+// planes and the two XYB planes arrive by LDS-DMA (global_load_lds_dwordx4: one instruction moves
+// 4 rows x 64 columns, no VGPRs) into a wave-private 2-group ring; group g+2 is requested as soon
+// as group g has been consumed, so one or two groups (7-14 KB per wave) are always in flight.
+// The filter's left tap (10 rows back) comes from a 16-deep register ring; the loop is unrolled
+// over 16 rows so every ring index is static.  No block barrier: waves only wait on vmcnt.
+constexpr int VB_G = 4;                       // rows per DMA group
+constexpr int VB_PLANES = 7;                  // 5 streams + xyb(ref) + xyb(test)
+constexpr int VB_SLOT = VB_G * 64;            // floats per plane per group
+constexpr int VB_GROUP = VB_PLANES * VB_SLOT; // floats per group
+
+template <int LEVEL>
+__global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict__ hbuf, const float *__restrict__ xyb,
+                                                        const uint32_t *__restrict__ pair_ref,
+                                                        double *__restrict__ partials, uint32_t w, uint32_t h,
+                                                        uint32_t pitch, size_t plane, uint32_t max_refs, uint32_t scale,
+                                                        uint32_t max_vblocks, rg_consts rg)
+{
+    __shared__ __attribute__((aligned(16))) float ring[2 * VB_GROUP];
+    const uint32_t lane = threadIdx.x, x0 = blockIdx.x * 64;
+    const uint32_t c = blockIdx.y, p = blockIdx.z;
+    const bool active = x0 + lane < w;
+    const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + x0;
+    const float *xa = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + x0;
+    const float *xb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + x0;
+    const uint32_t dr = lane >> 4, dc = (lane & 15) * 4;  // DMA: 16 lanes x 16 B per row, 4 rows per instruction
+
+    using gptr = const __attribute__((address_space(1))) void *;
+    using lptr = __attribute__((address_space(3))) void *;
+    // group g: rows 4g..4g+3 of the five streams and rows 4g-4..4g-1 of the XYB planes (what the
+    // steps of group g consume).  Rows outside the image are clamped (their values are never used).
+    auto issue_group = [&](int g) {
+        float *dst = ring + (g & 1) * VB_GROUP;
+        const uint32_t row = min((uint32_t)(4 * g) + dr, h - 1);
+        const size_t off = (size_t)row * pitch + dc;
+#pragma unroll
+        for (int s = 0; s < CE_SSIM2_STREAMS; s++)
+            __builtin_amdgcn_global_load_lds((gptr)(hb + (size_t)s * plane + off), (lptr)(dst + s * VB_SLOT), 16, 0, 0);
+        const int rx = 4 * g - 4 + (int)dr;
+        const size_t offx = (size_t)min((uint32_t)max(rx, 0), h - 1) * pitch + dc;
+        __builtin_amdgcn_global_load_lds((gptr)(xa + offx), (lptr)(dst + 5 * VB_SLOT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(xb + offx), (lptr)(dst + 6 * VB_SLOT), 16, 0, 0);
+    };
+
+    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3], rr[16][CE_SSIM2_STREAMS];
+#pragma unroll
+    for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) prev[s][k] = prev2[s][k] = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; e++) rr[e][s] = 0.0f;
+    }
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const float C2 = 0.0009f;
+    const uint32_t steps = h + 4;
+    const int n_groups = (int)((steps + VB_G - 1) / VB_G);
+
+    issue_group(0);
+    issue_group(1);
+    for (int g0 = 0; g0 < n_groups; g0 += 4) {
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++) {
+            const int g = g0 + gg;
+            if (g < n_groups) {
+                // group g has landed once at most the 7 requests of group g+1 are outstanding
+                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                const float *slot = ring + (gg & 1) * VB_GROUP + lane;
+#pragma unroll
+                for (int e = 0; e < VB_G; e++) {
+                    const uint32_t i = (uint32_t)(4 * g + e);
+                    constexpr int kDummy = 0;
+                    (void)kDummy;
+                    const int re = 4 * gg + e;  // i mod 16
+                    float v[CE_SSIM2_STREAMS];
+#pragma unroll
+                    for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
+                        const float ld = slot[s * VB_SLOT + e * 64];
+                        const float right = i < h ? ld : 0.0f;
+                        const float left = rr[(re + 6) & 15][s];  // row i-10
+                        rr[re][s] = right;
+                        v[s] = rg_step(left + right, prev[s], prev2[s], rg);
+                    }
+                    if (i >= 4 && i < steps) {
+                        const float img1 = slot[5 * VB_SLOT + e * 64], img2 = slot[6 * VB_SLOT + e * 64];
+                        const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
+                        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+                        const float mu_diff = mu1 - mu2;
+                        const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
+                        const float num_s = __builtin_fmaf(2.0f, s12 - mu12, C2);
+                        const float denom_s = (s11 - mu11) + (s22 - mu22) + C2;
+                        double d = 1.0 - (double)((num_m * num_s) / denom_s);
+                        if (!(d > 0.0)) d = 0.0;
+                        acc[0] += d;
+                        const double d2 = d * d;
+                        acc[1] += d2 * d2;
+                        const double d1 = (1.0 + (double)fabsf(img2 - mu2)) / (1.0 + (double)fabsf(img1 - mu1)) - 1.0;
+                        const double artifact = d1 > 0.0 ? d1 : 0.0;
+                        const double detail = -d1 > 0.0 ? -d1 : 0.0;
+                        acc[2] += artifact;
+                        const double a2 = artifact * artifact;
+                        acc[3] += a2 * a2;
+                        acc[4] += detail;
+                        const double l2 = detail * detail;
+                        acc[5] += l2 * l2;
+                    }
+                }
+                // this group's slot is free once its LDS reads have returned; refill it with group g+2
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue_group(g + 2);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land after the wave has retired
+    double *dst = partials + ((((size_t)p * CE_MAX_SCALES + scale) * 3 + c) * max_vblocks + blockIdx.x) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        const double sum = wave_sum(active ? acc[q] : 0.0);
+        if (lane == 0) dst[q] = sum;
+    }
+}
+
 __constant__ double c_weight[108] = {
     0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0, 1.1041726426657346, 0.00066284834129271, 0.00015231632783718752,
     0.0, 0.0016406437456599754, 0.0, 1.8422455520539298, 11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0, 1.8787594979546387, 10.94906990605142, 0.0,
@@ -578,6 +700,10 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                               rg_consts);
     static const hblur_fn kHblur[CE_MAX_SCALES] = {k_ssim2_hblur_lds<0>, k_ssim2_hblur_lds<1>, k_ssim2_hblur_lds<2>,
                                                    k_ssim2_hblur_lds<3>, k_ssim2_hblur_lds<4>, k_ssim2_hblur_lds<5>};
+    using vblur_fn = void (*)(const float *, const float *, const uint32_t *, double *, uint32_t, uint32_t, uint32_t,
+                              size_t, uint32_t, uint32_t, uint32_t, rg_consts);
+    static const vblur_fn kVblur[CE_MAX_SCALES] = {k_ssim2_vblur_dma<0>, k_ssim2_vblur_dma<1>, k_ssim2_vblur_dma<2>,
+                                                   k_ssim2_vblur_dma<3>, k_ssim2_vblur_dma<4>, k_ssim2_vblur_dma<5>};
     scale_geom g{};
     const int levels = std::min(b->n_scales, b->debug_max_scales);
     for (int s = 0; s < levels; s++) {
@@ -598,9 +724,8 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         CE_LAUNCH(ctx, kHName[s], kHblur[s], dim3((d.h + HB_ROWS - 1) / HB_ROWS, 3, n_pairs), dim3(HB_THREADS), 0,
                   b->d_xyb, b->d_pair_ref, b->d_hbuf, d.w, d.h, d.pitch, d.plane, b->max_refs, rg);
         const uint32_t nblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
-        CE_LAUNCH(ctx, kVName[s], k_ssim2_vblur_ssim, dim3(nblk, 3, n_pairs), dim3(kColsPerBlock), 0,
-                  b->d_hbuf, b->d_xyb, b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, d.hpitch, d.hplane,
-                  b->max_refs,
+        CE_LAUNCH(ctx, kVName[s], kVblur[s], dim3(nblk, 3, n_pairs), dim3(64), 0, b->d_hbuf, b->d_xyb, b->d_pair_ref,
+                  b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs,
                   (uint32_t)s, b->max_vblocks, rg);
         g.npix[s] = d.w * d.h;
         g.nblk[s] = nblk;
