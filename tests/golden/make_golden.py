@@ -1,0 +1,64 @@
+"""Regenerates tests/golden/{inputs.npz,scores.json}.
+
+The reference (Rust) cannot run here and its metric crates are not in the tree, so the vectors are
+produced by the CPU oracle (oracle/*.c) — they pin the ORACLE against accidental change and give the GPU
+tests fixed inputs; for PSNR and the XYB roundtrip (in-tree reference algorithms) they are true
+known-answer vectors.  Inputs are stored as data so the expected values do not depend on numpy/scipy
+versions.  Run:  python tests/golden/make_golden.py
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import oracle as O  # noqa: E402
+
+wl = importlib.import_module("codec-eval_amd.workloads")
+
+CASES = [  # name, w, h, seed, kind, quality, 4:2:0
+    ("nat64_q40", 64, 64, 11, "natural", 40, False),
+    ("nat64_q85", 64, 64, 11, "natural", 85, False),
+    ("nat100x76_q60", 100, 76, 12, "natural", 60, False),
+    ("nat97x131_q75_420", 97, 131, 13, "natural", 75, True),
+    ("noise48_q50", 48, 48, 14, "highfreq", 50, False),
+    ("flat40x56_q90", 40, 56, 15, "flat", 90, False),
+    ("nat192x128_q95", 192, 128, 16, "natural", 95, False),
+    ("nat192x128_q20", 192, 128, 16, "natural", 20, False),
+]
+
+
+def main():
+    arrays, scores = {}, {}
+    for name, w, h, seed, kind, q, s420 in CASES:
+        ref = wl.make_reference(w, h, seed, kind)
+        test = wl.distort(ref, q, s420)
+        arrays[name + ".ref"] = ref
+        arrays[name + ".test"] = test
+        rt = O.xyb_roundtrip(ref, w, h)
+        ba, ba3 = O.butteraugli(ref, test, w, h)
+        s2, avg = O.ssimulacra2_detail(ref, test, w, h, 1)
+        scores[name] = {
+            "width": w, "height": h,
+            "sse": O.sse(ref, test),
+            "psnr": O.psnr(ref, test, w, h),
+            "ssimulacra2": s2,
+            "ssimulacra2_fir": O.ssimulacra2(ref, test, w, h, 0),
+            "dssim": O.dssim(ref, test, w, h),
+            "butteraugli": ba, "butteraugli_3norm": ba3,
+            "xyb_roundtrip_sha256": hashlib.sha256(rt.tobytes()).hexdigest(),
+            "psnr_xyb_ref": O.psnr(rt, test, w, h),
+            "ssimulacra2_xyb_ref": O.ssimulacra2(rt, test, w, h, 1),
+        }
+    np.savez_compressed(os.path.join(HERE, "inputs.npz"), **arrays)
+    with open(os.path.join(HERE, "scores.json"), "w") as f:
+        json.dump(scores, f, indent=1, sort_keys=True)
+    print("wrote", len(CASES), "cases")
+
+
+if __name__ == "__main__":
+    main()
