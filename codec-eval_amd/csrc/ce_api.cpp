@@ -234,6 +234,7 @@ void ce_batch_destroy(ce_batch *b)
     hipFree(b->d_hbuf);
     hipFree(b->d_partials);
     hipFree(b->d_avg);
+    ce_dssim_free(b);
     delete b;
 }
 
@@ -318,8 +319,11 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         int rc = ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs);
         if (rc != CE_OK) return rc;
     }
-    if (metric_mask & (CE_METRIC_DSSIM | CE_METRIC_BUTTERAUGLI))
-        return fail(ctx, CE_ERR_BACKEND, "DSSIM / Butteraugli kernels are not built yet");
+    if (metric_mask & CE_METRIC_DSSIM) {
+        int rc = ce_launch_dssim(b, d_refs, n_refs_used, n_pairs);
+        if (rc != CE_OK) return rc;
+    }
+    if (metric_mask & CE_METRIC_BUTTERAUGLI) return fail(ctx, CE_ERR_BACKEND, "Butteraugli kernels are not built yet");
     b->last_n_pairs = n_pairs;
     b->last_mask = metric_mask;
     return CE_OK;
@@ -341,6 +345,10 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
         if (mask & CE_METRIC_PSNR) {
             s.psnr = psnr_from_sse(d.sse, b->w, b->h);
             s.valid |= CE_METRIC_PSNR;
+        }
+        if (mask & CE_METRIC_DSSIM) {
+            s.dssim = d.dssim;
+            s.valid |= CE_METRIC_DSSIM;
         }
         if (mask & CE_METRIC_SSIMULACRA2) {
             if (b->w < 8 || b->h < 8) {
@@ -511,8 +519,27 @@ int ce_xyb_roundtrip(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t wid
 int ce_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height,
                            float *rgba_out)
 {
-    (void)rgb; (void)rgb_len; (void)width; (void)height; (void)rgba_out;
-    return fail(ctx, CE_ERR_BACKEND, "rgb8_to_dssim_image: not built yet");
+    if (!ctx || !rgb || !rgba_out) return CE_ERR_INVALID_ARG;
+    if (rgb_len != width * height * 3) return fail(ctx, CE_ERR_BAD_LENGTH, "Buffer size mismatch");
+    const size_t n = width * height;
+    if (n == 0) return CE_OK;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_in = nullptr;
+    float *d_out = nullptr;
+    CE_HIP(ctx, hipMalloc(&d_in, rgb_len));
+    if (hipMalloc(&d_out, n * 4 * sizeof(float)) != hipSuccess) {
+        hipFree(d_in);
+        return fail(ctx, CE_ERR_BACKEND, "hipMalloc failed");
+    }
+    int rc = CE_OK;
+    if (hipMemcpy(d_in, rgb, rgb_len, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "H2D failed");
+    if (rc == CE_OK) rc = ce_launch_rgb8_to_dssim_image(ctx, d_in, d_out, n);
+    if (rc == CE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "sync failed");
+    if (rc == CE_OK && hipMemcpy(rgba_out, d_out, n * 4 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(ctx, CE_ERR_BACKEND, "D2H failed");
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
 }
 
 // ---- reference handle -------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 
 #define CE_MAX_SCALES 6      // SSIMULACRA2 pyramid depth
 #define CE_SSIM2_STREAMS 5   // blur(a), blur(b), blur(a*a), blur(b*b), blur(a*b)
+#define CE_DSSIM_SCALES 5    // dssim-core DEFAULT_WEIGHTS.len()
 
 struct ce_scale_dims {
     uint32_t w, h, pitch;  // pitch in floats, multiple of 32 (128-byte rows)
@@ -88,6 +89,22 @@ struct ce_batch {
     bool ssim2_ready = false;
     int debug_max_scales = CE_MAX_SCALES;  // test hook: stop the pyramid early
 
+    // DSSIM working set (dssim.hip); planes are [slot][3][plane] with the level's own geometry
+    struct dssim_level { uint32_t w, h, pitch; size_t plane; };
+    int ds_levels = 0;
+    dssim_level ds[CE_DSSIM_SCALES];
+    float *ds_lin[2] = {};     // linear RGB of the current and the next level
+    float *ds_img = nullptr;   // L, a', b' (chroma pre-blurred)
+    float *ds_mu = nullptr;    // blur(img)
+    float *ds_sq = nullptr;    // blur(img*img)
+    float *ds_tmp[2] = {};     // blur pass scratch
+    float *ds_i12 = nullptr;   // [pairs][3][plane] blur(img1*img2)
+    float *ds_map = nullptr;   // [pairs][plane] SSIM map
+    double *ds_part = nullptr; // [pairs][levels][2][blocks] partial sums (sum, abs-dev)
+    double *ds_level_scores = nullptr;  // [pairs][levels]
+    uint32_t ds_blocks = 0;
+    bool dssim_ready = false;
+
     uint32_t last_n_pairs = 0;
     uint32_t last_mask = 0;
 };
@@ -117,6 +134,9 @@ int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);
 int ce_ssim2_prepare(ce_batch *b);
 int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);
 int ce_launch_xyb_roundtrip(ce_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, size_t n_pixels);
+int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);
+void ce_dssim_free(ce_batch *b);
+int ce_launch_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *d_rgb, float *d_rgba, size_t n_pixels);
 
 // host-side constant builders (ce_tables.cpp)
 void ce_build_srgb_lut_f64(float lut[256]);

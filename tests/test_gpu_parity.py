@@ -245,3 +245,67 @@ def test_reference_handle(gpu_ctx, oracle, ce, workloads):
     with pytest.raises(ce.DimensionMismatch):
         hd.compare(ref[:10])
     hd.close()
+
+
+# ------------------------------------------------------------------------ DSSIM ----------------
+
+
+def test_dssim_reference_cases(gpu_ctx, oracle, ce):
+    # src/metrics/dssim.rs:180-273 (the reference feeds linear RGBA f32; the ABI takes RGB8 and stages on device)
+    img = gpu_ctx.rgb8_to_dssim_image(np.array([255, 0, 0, 0, 255, 0], np.uint8), 2, 1)
+    assert img.shape == (1, 2, 4) and abs(img[0, 0, 0] - 1.0) < 0.001 and abs(img[0, 1, 1] - 1.0) < 0.001
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, 37 * 29 * 3, dtype=np.uint8)
+    assert np.array_equal(gpu_ctx.rgb8_to_dssim_image(rgb, 37, 29), oracle.rgb8_to_dssim_image(rgb, 37, 29))  # bit-exact
+    grey = np.full(100 * 100 * 3, 128, np.uint8)
+    assert gpu_ctx.calculate_dssim(grey, grey, 100, 100) < 0.0001
+    a, b = np.full(30000, 77, np.uint8), np.full(30000, 180, np.uint8)
+    got = gpu_ctx.calculate_dssim(a, b, 100, 100)
+    assert got > 0.0 and rel_close(got, oracle.dssim(a, b, 100, 100), floor=1e-6)
+    with pytest.raises(ce.DimensionMismatch):
+        gpu_ctx.calculate_dssim(np.zeros(50 * 50 * 3, np.uint8), grey, 100, 100)
+
+
+DSSIM_SHAPES = [(1, 1), (3, 2), (7, 9), (8, 8), (15, 17), (20, 20), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512), (512, 768)]
+
+
+@pytest.mark.parametrize("w,h", DSSIM_SHAPES)
+def test_dssim_parity_shapes(gpu_ctx, oracle, ce, workloads, w, h):
+    ref = workloads.make_reference(w, h, 300 + w)
+    for q in (30, 75, 95):
+        test = workloads.distort(ref, q)
+        want = oracle.dssim(ref, test, w, h)
+        got = gpu_ctx.calculate_dssim(ref, test, w, h)
+        # planes are bit-identical; only the f64 summation order differs
+        assert abs(got - want) <= 1e-9 * max(abs(want), 1e-6), (w, h, q, got, want)
+    assert gpu_ctx.calculate_dssim(ref, ref, w, h) == 0.0
+
+
+def test_dssim_in_mixed_metric_batch(gpu_ctx, oracle, ce, workloads):
+    w, h = 128, 96
+    refs = [workloads.make_reference(w, h, 50 + i) for i in range(2)]
+    pairs = [(refs[i], workloads.distort(refs[i], q), w, h) for i in range(2) for q in (40, 70, 90)]
+    cfg = ce.MetricConfig(dssim=True, ssimulacra2=True, psnr=True)
+    out = gpu_ctx.eval_batch(pairs, cfg)
+    for (r, t, _, _), s in zip(pairs, out):
+        assert s.status == 0 and s.valid == (ce.METRIC_DSSIM | ce.METRIC_SSIMULACRA2 | ce.METRIC_PSNR)
+        assert s.psnr == oracle.psnr(r, t, w, h)
+        assert rel_close(s.ssimulacra2, oracle.ssimulacra2(r, t, w, h, 1))
+        assert rel_close(s.dssim, oracle.dssim(r, t, w, h), floor=1e-6)
+    # xyb_roundtrip flag applies to the reference of every metric
+    got = gpu_ctx.calculate_metrics(refs[0], pairs[0][1], w, h, ce.MetricConfig(dssim=True, xyb_roundtrip=True))
+    assert rel_close(got.dssim, oracle.dssim(oracle.xyb_roundtrip(refs[0], w, h), pairs[0][1], w, h), floor=1e-6)
+    assert got.perception_level() == ce.perception_from_dssim(got.dssim)
+
+
+def test_helpers_mirror_dssim(gpu_ctx, ce):
+    # src/eval/helpers.rs:337-383
+    img, shifted = helper_pattern(64, 64, 0), helper_pattern(64, 64, 50)
+    res = ce.evaluate_single(gpu_ctx, img, img, ce.MetricConfig(dssim=True, ssimulacra2=True))
+    assert res.dssim < 0.0001 and res.ssimulacra2 > 99.0
+    ce.assert_quality(gpu_ctx, img, img, 90.0, 0.001)
+    ce.assert_perception_level(gpu_ctx, img, img, "Imperceptible")
+    with pytest.raises(ce.QualityBelowThreshold):
+        ce.assert_perception_level(gpu_ctx, img, shifted, "Imperceptible")
+    with pytest.raises(ce.QualityBelowThreshold):
+        ce.assert_quality(gpu_ctx, img, shifted, None, 0.0001)
