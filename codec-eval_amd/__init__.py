@@ -116,6 +116,7 @@ _PROTOTYPES = [
     ("ce_batch_run", _i, [_vp, _u32, _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_batch_launch", _i, [_vp, _u32, _u32, _u32, _f32]),
     ("ce_batch_collect", _i, [_vp, _u32, C.POINTER(CeScores)]),
+    ("ce_batch_butteraugli_pnorm3", _i, [_vp, _u32, _dp]),
     ("ce_ref_create", _i, [_vp, _u8p, _sz, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("ce_ref_compare", _i, [_vp, _u8p, _sz, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_ref_destroy", None, [_vp]),
@@ -441,6 +442,11 @@ class Batch:
         out = (CeScores * n_pairs)()
         self.ctx._check(lib().ce_batch_collect(self._h, n_pairs, out))
         return list(out)
+
+    def butteraugli_pnorm3(self, n_pairs: int) -> np.ndarray:
+        out = np.zeros(n_pairs, np.float64)
+        self.ctx._check(lib().ce_batch_butteraugli_pnorm3(self._h, n_pairs, out.ctypes.data_as(_dp)))
+        return out
 
     # -- test hooks
     def debug_limit_scales(self, n: int):

@@ -1,0 +1,779 @@
+// Butteraugli on gfx950 — replaces butteraugli::butteraugli(..).score behind
+// /root/reference/src/metrics/butteraugli.rs:72-80,127-135 (and compute_butteraugli(..).score in the
+// codec-compare bins).  Restates libjxl's butteraugli.cc pipeline stage by stage, in the same f32
+// operation order as the CPU restatement (oracle/butteraugli.c):
+//
+//   per image slot and resolution level (full, 2x-subsampled) — the "PsychoImage", built once per
+//   reference, not once per pair:
+//     sRGB u8 -> linear -> blur sigma 1.2 (5-tap, mirrored) -> OpsinDynamicsImage -> XYB
+//     -> LF = blur 7.156 ; MF = blur 3.225 of (XYB - LF) ; HF = blur 1.564 of the rest ; UHF = rest,
+//        with the range shaping of SeparateFrequencies -> 10 planes
+//   per pair and level:
+//     Malta line filters (UHF, HF, MF; X and Y), asymmetric L2 (HF), L2 (MF), L2 (LF), mask from
+//     HF+UHF (blur 2.7, fuzzy erosion), CombineChannelsToDiffmap
+//   then diffmap = 0.85 * full + 0.5 * upsampled(half) ; score = max ; p-norm = mean of 3-, 6-, 12-norms.
+//
+// Long blurs (33 / 15 / 13 / 7 taps, borders re-normalised) read their taps straight from global
+// memory: for a fixed tap the 64 lanes of a wave read 64 consecutive floats, so every request is
+// coalesced and the tap re-reads are L1/L2 hits.  Build with -ffp-contract=off.
+#include <algorithm>
+#include <cmath>
+
+#include "ce_internal.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int PSY = 10;  // uhf0 uhf1 hf0 hf1 mf0 mf1 mf2 lf0 lf1 lf2
+enum { UHF0 = 0, UHF1, HF0, HF1, MF0, MF1, MF2, LF0, LF1, LF2 };
+
+struct geom {
+    uint32_t w, h, pitch;
+    size_t plane;
+};
+
+struct blur_kernel {
+    int len;
+    float k[40];
+};
+
+#define BA_XY                                                           \
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);            \
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);             \
+    if (x >= g.w || y >= g.h) return;                                   \
+    const size_t o = (size_t)y * g.pitch + x
+
+__device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, uint32_t max_refs)
+{
+    return z < n_refs_used ? z : max_refs + (z - n_refs_used);
+}
+
+// ---- sRGB u8 -> linear planes -----------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_ba_linear_u8(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
+                                                      const float *__restrict__ lut, float *__restrict__ lin, geom g,
+                                                      size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+{
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
+    BA_XY;
+    const uint8_t *px = src + ((size_t)y * g.w + x) * 3;
+    float *dst = lin + (size_t)slot * 3 * g.plane + o;
+    dst[0] = s_lut[px[0]];
+    dst[g.plane] = s_lut[px[1]];
+    dst[2 * g.plane] = s_lut[px[2]];
+}
+
+// ---- SubSample2x: out(x/2, y/2) += 0.25 * in(x, y) in raster order; odd edges doubled ------------------
+__global__ __launch_bounds__(TPB) void k_ba_subsample2x(const float *__restrict__ in, float *__restrict__ out, geom gi, geom g,
+                                                        uint32_t n_refs_used, uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs), c = blockIdx.z % 3;
+    BA_XY;
+    const float *p = in + ((size_t)slot * 3 + c) * gi.plane;
+    float acc = 0.0f;
+#pragma unroll
+    for (uint32_t dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (uint32_t dx = 0; dx < 2; dx++) {
+            const uint32_t ix = 2 * x + dx, iy = 2 * y + dy;
+            if (ix < gi.w && iy < gi.h) acc += 0.25f * p[(size_t)iy * gi.pitch + ix];
+        }
+    if ((gi.w & 1) && x == g.w - 1) acc *= 2.0f;
+    if ((gi.h & 1) && y == g.h - 1) acc *= 2.0f;
+    out[((size_t)slot * 3 + c) * g.plane + o] = acc;
+}
+
+// ---- separable blurs ------------------------------------------------------------------------------------
+// unit stride `us` planes per unit; planes [first, first+n) of each unit are processed; z = unit * n + k
+struct plane_sel {
+    uint32_t per_unit, first, n;
+};
+
+__device__ __forceinline__ uint32_t mirror(int x, int n)
+{
+    while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
+    return (uint32_t)x;
+}
+
+template <bool VERT>
+__global__ __launch_bounds__(TPB) void k_ba_blur5_mirror(const float *__restrict__ in, float *__restrict__ out, geom g,
+                                                         plane_sel si, plane_sel so, float w0, float w1, float w2,
+                                                         uint32_t n_refs_used, uint32_t max_refs, int by_slot)
+{
+    const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
+    const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
+    BA_XY;
+    const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
+    float r;
+    if (!VERT) {
+        const float *row = p + (size_t)y * g.pitch;
+        const int X = (int)x, W = (int)g.w;
+        r = row[x] * w0 + (row[mirror(X - 1, W)] + row[mirror(X + 1, W)]) * w1 + (row[mirror(X - 2, W)] + row[mirror(X + 2, W)]) * w2;
+    } else {
+        const int Y = (int)y, H = (int)g.h;
+        const float *col = p + x;
+        r = col[(size_t)y * g.pitch] * w0 +
+            (col[(size_t)mirror(Y - 1, H) * g.pitch] + col[(size_t)mirror(Y + 1, H) * g.pitch]) * w1 +
+            (col[(size_t)mirror(Y - 2, H) * g.pitch] + col[(size_t)mirror(Y + 2, H) * g.pitch]) * w2;
+    }
+    out[((size_t)unit * so.per_unit + so.first + k) * g.plane + o] = r;
+}
+
+template <bool VERT>
+__global__ __launch_bounds__(TPB) void k_ba_blur(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
+                                                 plane_sel so, blur_kernel bk, uint32_t n_refs_used, uint32_t max_refs,
+                                                 int by_slot)
+{
+    const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
+    const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
+    BA_XY;
+    const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
+    const int off = bk.len / 2;
+    const int pos = VERT ? (int)y : (int)x, n = VERT ? (int)g.h : (int)g.w;
+    const int lo = max(pos - off, 0), hi = min(pos + off, n - 1);
+    const float *base = VERT ? p + x : p + (size_t)y * g.pitch;
+    const size_t stride = VERT ? g.pitch : 1;
+    float sum = 0.0f, r;
+    if (lo == pos - off && hi == pos + off) {
+        float wsum = 0.0f;
+        for (int j = 0; j < bk.len; j++) wsum += bk.k[j];
+        for (int j = lo; j <= hi; j++) sum += base[(size_t)j * stride] * bk.k[j - pos + off];
+        r = sum * (1.0f / wsum);
+    } else {
+        float weight = 0.0f;
+        for (int j = lo; j <= hi; j++) weight += bk.k[j - pos + off];
+        const float scale = 1.0f / weight;
+        for (int j = lo; j <= hi; j++) sum += base[(size_t)j * stride] * bk.k[j - pos + off];
+        r = sum * scale;
+    }
+    out[((size_t)unit * so.per_unit + so.first + k) * g.plane + o] = r;
+}
+
+// ---- OpsinDynamicsImage (pointwise part) ---------------------------------------------------------------
+__device__ __forceinline__ void opsin_absorbance(float in0, float in1, float in2, float &o0, float &o1, float &o2)
+{
+    const float mixi0 = 0.29956550340058319f, mixi1 = 0.63373087833825936f, mixi2 = 0.077705617820981968f, mixi3 = 1.7557483643287353f;
+    const float mixi4 = 0.22158691104574774f, mixi5 = 0.69391388044116142f, mixi6 = 0.0987313588422f, mixi7 = 1.7557483643287353f;
+    const float mixi8 = 0.02f, mixi9 = 0.02f, mixi10 = 0.20480129041026129f, mixi11 = 12.226454707163354f;
+    o0 = __builtin_fmaf(mixi0, in0, __builtin_fmaf(mixi1, in1, __builtin_fmaf(mixi2, in2, mixi3)));
+    o1 = __builtin_fmaf(mixi4, in0, __builtin_fmaf(mixi5, in1, __builtin_fmaf(mixi6, in2, mixi7)));
+    o2 = __builtin_fmaf(mixi8, in0, __builtin_fmaf(mixi9, in1, __builtin_fmaf(mixi10, in2, mixi11)));
+}
+
+__device__ __forceinline__ float gamma_f(float v)
+{
+    const float kRetMul = 19.245013259874995f * 0.693147180559945f, kRetAdd = -23.16046239805755f;
+    if (v < 0.0f) v = 0.0f;
+    const float biased = v + 9.9710635769299145f;
+    return __builtin_fmaf(kRetMul, log2f(biased), kRetAdd);
+}
+
+__global__ __launch_bounds__(TPB) void k_ba_opsin(const float *__restrict__ lin, const float *__restrict__ blurred,
+                                                  float *__restrict__ xyb, geom g, float intensity_target, uint32_t n_refs_used,
+                                                  uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
+    BA_XY;
+    const size_t b = (size_t)slot * 3 * g.plane + o;
+    const float mn = 1e-4f;
+    float p0, p1, p2;
+    opsin_absorbance(blurred[b] * intensity_target, blurred[b + g.plane] * intensity_target,
+                     blurred[b + 2 * g.plane] * intensity_target, p0, p1, p2);
+    p0 = p0 > mn ? p0 : mn;
+    p1 = p1 > mn ? p1 : mn;
+    p2 = p2 > mn ? p2 : mn;
+    float s0 = gamma_f(p0) / p0, s1 = gamma_f(p1) / p1, s2 = gamma_f(p2) / p2;
+    s0 = s0 > mn ? s0 : mn;
+    s1 = s1 > mn ? s1 : mn;
+    s2 = s2 > mn ? s2 : mn;
+    float c0, c1, c2;
+    opsin_absorbance(lin[b] * intensity_target, lin[b + g.plane] * intensity_target, lin[b + 2 * g.plane] * intensity_target, c0,
+                     c1, c2);
+    c0 *= s0;
+    c1 *= s1;
+    c2 *= s2;
+    const float min01 = 1.7557483643287353f, min2 = 12.226454707163354f;
+    c0 = c0 > min01 ? c0 : min01;
+    c1 = c1 > min01 ? c1 : min01;
+    c2 = c2 > min2 ? c2 : min2;
+    xyb[b] = c0 - c1;
+    xyb[b + g.plane] = c0 + c1;
+    xyb[b + 2 * g.plane] = c2;
+}
+
+// ---- SeparateFrequencies pointwise stages ------------------------------------------------------------------
+__device__ __forceinline__ float remove_range(float w, float x) { return x > w ? x - w : (x < -w ? x + w : 0.0f); }
+__device__ __forceinline__ float amplify_range(float w, float x) { return x > w ? x + w : (x < -w ? x - w : x + x); }
+__device__ __forceinline__ float maximum_clamp(float v, float maxval)
+{
+    const float kMul = 0.724216145665f;
+    if (v >= maxval) return __builtin_fmaf(v - maxval, kMul, maxval);
+    if (v < -maxval) return __builtin_fmaf(v + maxval, kMul, -maxval);
+    return v;
+}
+
+// mf_raw = xyb - lf  (into the three MF planes of the psycho image)
+__global__ __launch_bounds__(TPB) void k_ba_mf_raw(const float *__restrict__ xyb, float *__restrict__ psy, geom g,
+                                                   uint32_t n_refs_used, uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs), c = blockIdx.z % 3;
+    BA_XY;
+    float *ps = psy + (size_t)slot * PSY * g.plane + o;
+    ps[(MF0 + c) * g.plane] = xyb[((size_t)slot * 3 + c) * g.plane + o] - ps[(LF0 + c) * g.plane];
+}
+
+// mf_raw (psy MF) and mf_blur (scratch) -> hf_raw, shaped mf; X gets SuppressXByY; B keeps the blur only
+__global__ __launch_bounds__(TPB) void k_ba_split_mf(const float *__restrict__ mf_blur, float *__restrict__ psy, geom g,
+                                                     uint32_t n_refs_used, uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
+    BA_XY;
+    float *ps = psy + (size_t)slot * PSY * g.plane + o;
+    const float *mb = mf_blur + (size_t)slot * 3 * g.plane + o;
+    const float kRemoveMfRange = 0.29f, kAddMfRange = 0.1f;
+    float hf[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        float mf = mb[c * g.plane];
+        hf[c] = ps[(MF0 + c) * g.plane] - mf;
+        mf = c == 0 ? remove_range(kRemoveMfRange, mf) : amplify_range(kAddMfRange, mf);
+        ps[(MF0 + c) * g.plane] = mf;
+    }
+    ps[MF2 * g.plane] = mb[2 * g.plane];
+    // SuppressXByY(hf[1], &hf[0])
+    const float suppress = 46.0f, s = 0.653020556257f, one_minus_s = 1.0f - 0.653020556257f;
+    const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf[1], hf[1], suppress), one_minus_s, s);
+    ps[HF0 * g.plane] = scaler * hf[0];
+    ps[HF1 * g.plane] = hf[1];
+}
+
+// hf_raw (psy HF) and hf_blur (scratch, 2 planes per slot) -> hf, uhf
+__global__ __launch_bounds__(TPB) void k_ba_split_hf(const float *__restrict__ hf_blur, float *__restrict__ psy, geom g,
+                                                     uint32_t n_refs_used, uint32_t max_refs)
+{
+    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
+    BA_XY;
+    float *ps = psy + (size_t)slot * PSY * g.plane + o;
+    const float *hb = hf_blur + (size_t)slot * 3 * g.plane + o;
+    const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
+    const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
+    {
+        float hf = hb[0];
+        float uhf = ps[HF0 * g.plane] - hf;
+        ps[HF0 * g.plane] = remove_range(kRemoveHfRange, hf);
+        ps[UHF0 * g.plane] = remove_range(kRemoveUhfRange, uhf);
+    }
+    {
+        float hf = maximum_clamp(hb[g.plane], kMaxclampHf);
+        float uhf = ps[HF1 * g.plane] - hf;
+        uhf = maximum_clamp(uhf, kMaxclampUhf);
+        uhf *= kMulYUhf;
+        ps[UHF1 * g.plane] = uhf;
+        hf *= kMulYHf;
+        ps[HF1 * g.plane] = amplify_range(kAddHfRange, hf);
+    }
+    // XybLowFreqToVals, in place on lf
+    const float xmul = 33.832837186260f, ymul = 14.458268100570f, bmul = 49.87984651440f, y_to_b_mul = -0.362267051518f;
+    const float lx = ps[LF0 * g.plane], ly = ps[LF1 * g.plane], lb = ps[LF2 * g.plane];
+    const float bb = __builtin_fmaf(y_to_b_mul, ly, lb);
+    ps[LF2 * g.plane] = bb * bmul;
+    ps[LF0 * g.plane] = lx * xmul;
+    ps[LF1 * g.plane] = ly * ymul;
+}
+
+// ---- per pair: Malta ----------------------------------------------------------------------------------------
+struct malta_params {
+    float norm2_0gt1, norm2_0lt1, norm1;
+};
+
+__global__ __launch_bounds__(TPB) void k_ba_malta_diffs(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+                                                        float *__restrict__ diffs, geom g, uint32_t max_refs, uint32_t plane_idx,
+                                                        malta_params mp)
+{
+    const uint32_t p = blockIdx.z;
+    BA_XY;
+    const float v0 = psy[((size_t)pair_ref[p] * PSY + plane_idx) * g.plane + o];
+    const float v1 = psy[((size_t)(max_refs + p) * PSY + plane_idx) * g.plane + o];
+    const float absval = 0.5f * (fabsf(v0) + fabsf(v1));
+    const float diff = v0 - v1;
+    const float scaler = mp.norm2_0gt1 / (mp.norm1 + absval);
+    float r = scaler * diff;
+    const float scaler2 = mp.norm2_0lt1 / (mp.norm1 + absval);
+    const double fabs0 = fabs((double)v0);
+    const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
+    if (v0 < 0) {
+        if (v1 > -too_small) {
+            const double impact = scaler2 * (v1 + too_small);
+            r = (float)(r - impact);
+        } else if (v1 < -too_big) {
+            const double impact = scaler2 * (-v1 - too_big);
+            r = (float)(r + impact);
+        }
+    } else {
+        if (v1 < too_small) {
+            const double impact = scaler2 * (too_small - v1);
+            r = (float)(r + impact);
+        } else if (v1 > too_big) {
+            const double impact = scaler2 * (v1 - too_big);
+            r = (float)(r - impact);
+        }
+    }
+    diffs[(size_t)p * g.plane + o] = r;
+}
+
+struct mline {
+    int n;
+    signed char d[9][2];
+};
+
+__device__ constexpr mline MALTA_HF[16] = {
+    {9, {{-4, 0}, {-3, 0}, {-2, 0}, {-1, 0}, {0, 0}, {1, 0}, {2, 0}, {3, 0}, {4, 0}}},
+    {9, {{0, -4}, {0, -3}, {0, -2}, {0, -1}, {0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}}},
+    {7, {{-3, -3}, {-2, -2}, {-1, -1}, {0, 0}, {1, 1}, {2, 2}, {3, 3}}},
+    {7, {{3, -3}, {2, -2}, {1, -1}, {0, 0}, {-1, 1}, {-2, 2}, {-3, 3}}},
+    {9, {{1, -4}, {1, -3}, {1, -2}, {0, -1}, {0, 0}, {0, 1}, {-1, 2}, {-1, 3}, {-1, 4}}},
+    {9, {{-1, -4}, {-1, -3}, {-1, -2}, {0, -1}, {0, 0}, {0, 1}, {1, 2}, {1, 3}, {1, 4}}},
+    {9, {{-4, -1}, {-3, -1}, {-2, -1}, {-1, 0}, {0, 0}, {1, 0}, {2, 1}, {3, 1}, {4, 1}}},
+    {9, {{-4, 1}, {-3, 1}, {-2, 1}, {-1, 0}, {0, 0}, {1, 0}, {2, -1}, {3, -1}, {4, -1}}},
+    {7, {{-2, -3}, {-1, -2}, {-1, -1}, {0, 0}, {1, 1}, {1, 2}, {2, 3}}},
+    {7, {{2, -3}, {1, -2}, {1, -1}, {0, 0}, {-1, 1}, {-1, 2}, {-2, 3}}},
+    {7, {{-3, -2}, {-2, -1}, {-1, -1}, {0, 0}, {1, 1}, {2, 1}, {3, 2}}},
+    {7, {{3, -2}, {2, -1}, {1, -1}, {0, 0}, {-1, 1}, {-2, 1}, {-3, 2}}},
+    {8, {{-4, 2}, {-3, 2}, {-2, 1}, {-1, 1}, {0, 0}, {1, 0}, {2, -1}, {3, -1}}},
+    {8, {{-4, -2}, {-3, -2}, {-2, -1}, {-1, -1}, {0, 0}, {1, 0}, {2, 1}, {3, 1}}},
+    {8, {{-2, -4}, {-2, -3}, {-1, -2}, {-1, -1}, {0, 0}, {0, 1}, {1, 2}, {1, 3}}},
+    {8, {{2, -4}, {2, -3}, {1, -2}, {1, -1}, {0, 0}, {0, 1}, {-1, 2}, {-1, 3}}},
+};
+__device__ constexpr mline MALTA_LF[16] = {
+    {5, {{-4, 0}, {-2, 0}, {0, 0}, {2, 0}, {4, 0}}},
+    {5, {{0, -4}, {0, -2}, {0, 0}, {0, 2}, {0, 4}}},
+    {5, {{-3, -3}, {-2, -2}, {0, 0}, {2, 2}, {3, 3}}},
+    {5, {{3, -3}, {2, -2}, {0, 0}, {-2, 2}, {-3, 3}}},
+    {5, {{1, -4}, {1, -2}, {0, 0}, {-1, 2}, {-1, 4}}},
+    {5, {{-1, -4}, {-1, -2}, {0, 0}, {1, 2}, {1, 4}}},
+    {5, {{-4, -1}, {-2, -1}, {0, 0}, {2, 1}, {4, 1}}},
+    {5, {{-4, 1}, {-2, 1}, {0, 0}, {2, -1}, {4, -1}}},
+    {5, {{-2, -3}, {-1, -2}, {0, 0}, {1, 2}, {2, 3}}},
+    {5, {{2, -3}, {1, -2}, {0, 0}, {-1, 2}, {-2, 3}}},
+    {5, {{-3, -2}, {-2, -1}, {0, 0}, {2, 1}, {3, 2}}},
+    {5, {{3, -2}, {2, -1}, {0, 0}, {-2, 1}, {-3, 2}}},
+    {5, {{-4, 2}, {-2, 1}, {0, 0}, {2, -1}, {4, -2}}},
+    {5, {{-4, -2}, {-2, -1}, {0, 0}, {2, 1}, {4, 2}}},
+    {5, {{-2, -4}, {-1, -2}, {0, 0}, {1, 2}, {2, 4}}},
+    {5, {{2, -4}, {1, -2}, {0, 0}, {-1, 2}, {-2, 4}}},
+};
+
+// 32x32 outputs per block from a zero-padded 40x40 LDS tile; ac += sum over 16 lines of (line sum)^2
+constexpr int MT = 32, MH = 4, ML = MT + 2 * MH;
+template <bool LF>
+__global__ __launch_bounds__(TPB) void k_ba_malta(const float *__restrict__ diffs, float *__restrict__ ac, geom g)
+{
+    __shared__ float s[ML * ML];
+    const uint32_t p = blockIdx.z;
+    const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MT - MH;
+    const float *d = diffs + (size_t)p * g.plane;
+    for (int i = threadIdx.x; i < ML * ML; i += TPB) {
+        const int lx = i % ML, ly = i / ML, gx = x0 + lx, gy = y0 + ly;
+        s[i] = (gx >= 0 && gy >= 0 && gx < (int)g.w && gy < (int)g.h) ? d[(size_t)gy * g.pitch + gx] : 0.0f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ty = ty0 + 8 * r;
+        const uint32_t x = blockIdx.x * MT + tx, y = blockIdx.y * MT + ty;
+        if (x >= g.w || y >= g.h) continue;
+        const float *c = s + (ty + MH) * ML + tx + MH;
+        float ret = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const mline &ln = LF ? MALTA_LF[k] : MALTA_HF[k];
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 9; j++)
+                if (j < ln.n) sum += c[ln.d[j][1] * ML + ln.d[j][0]];
+            ret = __builtin_fmaf(sum, sum, ret);
+        }
+        ac[(size_t)p * g.plane + (size_t)y * g.pitch + x] += ret;
+    }
+}
+
+// ---- per pair: L2 terms (fills dc[0..2], adds to ac[0..2]) -----------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_ba_l2(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+                                               float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
+                                               uint32_t n_pairs_stride)
+{
+    const uint32_t p = blockIdx.z;
+    BA_XY;
+    const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane + o;
+    const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane + o;
+    const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
+    const float hf_asymmetry = 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float *pac = ac + ((size_t)c * n_pairs_stride + p) * g.plane + o;
+        float total = *pac;
+        if (c < 2) {  // L2DiffAsymmetric on hf[c]
+            const float w_0gt1 = wmul[c] * hf_asymmetry, w_0lt1 = wmul[c] / hf_asymmetry;
+            const float vw_0gt1 = w_0gt1 * 0.8f, vw_0lt1 = w_0lt1 * 0.8f;
+            const float val0 = a[(HF0 + c) * g.plane], val1 = b[(HF0 + c) * g.plane];
+            const float diff = val0 - val1;
+            total = __builtin_fmaf(diff * diff, vw_0gt1, total);
+            const float fabs0 = fabsf(val0);
+            const float too_small = 0.4f * fabs0, too_big = fabs0;
+            const float if_neg = val1 > -too_small ? val1 + too_small : (val1 < -too_big ? -val1 - too_big : 0.0f);
+            const float if_pos = val1 < too_small ? too_small - val1 : (val1 > too_big ? val1 - too_big : 0.0f);
+            const float v = val0 < 0.0f ? if_neg : if_pos;
+            total = __builtin_fmaf(vw_0lt1, v * v, total);
+        }
+        {  // L2Diff on mf[c]
+            const float diff = a[(MF0 + c) * g.plane] - b[(MF0 + c) * g.plane];
+            total = __builtin_fmaf(diff * diff, wmul[3 + c], total);
+        }
+        *pac = total;
+        {  // SetL2Diff on lf[c]
+            const float diff = a[(LF0 + c) * g.plane] - b[(LF0 + c) * g.plane];
+            dc[((size_t)c * n_pairs_stride + p) * g.plane + o] = (diff * diff) * wmul[6 + c];
+        }
+    }
+}
+
+// ---- per pair: mask -----------------------------------------------------------------------------------------------
+// which = 0: reference image, 1: test image.  out = DiffPrecompute(sqrt(xdiff^2 + ydiff^2))
+__global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+                                                     float *__restrict__ out, geom g, uint32_t max_refs, int which)
+{
+    const uint32_t p = blockIdx.z;
+    BA_XY;
+    const float *a = psy + (size_t)(which ? max_refs + p : pair_ref[p]) * PSY * g.plane + o;
+    const float muls[3] = {2.5f, 0.4f, 0.4f};
+    const float xdiff = (a[UHF0 * g.plane] + a[HF0 * g.plane]) * muls[0];
+    const float ydiff = a[UHF1 * g.plane] * muls[1] + a[HF1 * g.plane] * muls[2];
+    const float m = sqrtf(xdiff * xdiff + ydiff * ydiff);
+    const float kMul = 6.19424080439f, kBias = 12.61050594197f;
+    const float bias = kMul * kBias;
+    const float sqrt_bias = sqrtf(bias);
+    out[(size_t)p * g.plane + o] = sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
+}
+
+__device__ __forceinline__ void store_min3(float v, float &min0, float &min1, float &min2)
+{
+    if (v < min2) {
+        if (v < min0) {
+            min2 = min1;
+            min1 = min0;
+            min0 = v;
+        } else if (v < min1) {
+            min2 = min1;
+            min1 = v;
+        } else {
+            min2 = v;
+        }
+    }
+}
+
+// mask = FuzzyErosion(blurred0);  ac[1] += 10 (blurred0 - blurred1)^2
+__global__ __launch_bounds__(TPB) void k_ba_mask_finish(const float *__restrict__ bl0, const float *__restrict__ bl1,
+                                                        float *__restrict__ mask, float *__restrict__ ac1, geom g)
+{
+    const uint32_t p = blockIdx.z;
+    BA_XY;
+    const float *from = bl0 + (size_t)p * g.plane;
+    const int X = (int)x, Y = (int)y, W = (int)g.w, H = (int)g.h, S = 3;
+    auto at = [&](int yy, int xx) { return from[(size_t)yy * g.pitch + xx]; };
+    float min0 = at(Y, X), min1 = 2 * min0, min2 = min1;
+    if (X >= S) {
+        store_min3(at(Y, X - S), min0, min1, min2);
+        if (Y >= S) store_min3(at(Y - S, X - S), min0, min1, min2);
+        if (Y < H - S) store_min3(at(Y + S, X - S), min0, min1, min2);
+    }
+    if (X < W - S) {
+        store_min3(at(Y, X + S), min0, min1, min2);
+        if (Y >= S) store_min3(at(Y - S, X + S), min0, min1, min2);
+        if (Y < H - S) store_min3(at(Y + S, X + S), min0, min1, min2);
+    }
+    if (Y >= S) store_min3(at(Y - S, X), min0, min1, min2);
+    if (Y < H - S) store_min3(at(Y + S, X), min0, min1, min2);
+    mask[(size_t)p * g.plane + o] = 0.45f * min0 + 0.3f * min1 + 0.25f * min2;
+    const float diff = at(Y, X) - bl1[(size_t)p * g.plane + o];
+    ac1[(size_t)p * g.plane + o] += 10.0f * diff * diff;
+}
+
+// ---- CombineChannelsToDiffmap --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_ba_combine(const float *__restrict__ mask, const float *__restrict__ ac,
+                                                    const float *__restrict__ dc, float *__restrict__ diffmap, geom g,
+                                                    uint32_t n_pairs_stride)
+{
+    const uint32_t p = blockIdx.z;
+    BA_XY;
+    const double kGlobalScale = 1.0 / (17.83 * 0.790799174);
+    const double val = (double)mask[(size_t)p * g.plane + o];
+    double c = 2.5485944793 / ((0.451936922203 * val) + 0.829591754942);
+    double rv = kGlobalScale * (1.0 + c);
+    const float maskval = (float)(rv * rv);
+    c = 0.505054525019 / ((3.87449418804 * val) + 0.20025578522);
+    rv = kGlobalScale * (1.0 + c);
+    const float dc_maskval = (float)(rv * rv);
+    float d_ac[3], d_dc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d_ac[k] = ac[((size_t)k * n_pairs_stride + p) * g.plane + o];
+        d_dc[k] = dc[((size_t)k * n_pairs_stride + p) * g.plane + o];
+    }
+    const float xmul = 1.0f;
+    d_ac[0] *= xmul;
+    d_dc[0] *= xmul;
+    const float mc_dc = d_dc[0] * dc_maskval + d_dc[1] * dc_maskval + d_dc[2] * dc_maskval;
+    const float mc_ac = d_ac[0] * maskval + d_ac[1] * maskval + d_ac[2] * maskval;
+    diffmap[(size_t)p * g.plane + o] = sqrtf(mc_dc + mc_ac);
+}
+
+__global__ __launch_bounds__(TPB) void k_ba_zero(float *__restrict__ buf, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) buf[i] = 0.0f;
+}
+
+// AddSupersampled2x (weight 0.5) fused with the final reductions: max, sum d^3, d^6, d^12
+__global__ __launch_bounds__(TPB) void k_ba_final(float *__restrict__ diffmap, const float *__restrict__ sub, geom g, geom gs,
+                                                  int has_sub, float *__restrict__ blk_max, double *__restrict__ blk_sums,
+                                                  uint32_t n_blocks)
+{
+    __shared__ float s_max[TPB / 64];
+    __shared__ double s_sum[3][TPB / 64];
+    const uint32_t p = blockIdx.z;
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    float d = 0.0f;
+    double s3 = 0.0, s6 = 0.0, s12 = 0.0;
+    if (x < g.w && y < g.h) {
+        const size_t o = (size_t)p * g.plane + (size_t)y * g.pitch + x;
+        d = diffmap[o];
+        if (has_sub) {
+            const float kHeuristicMixingValue = 0.3f, wgt = 0.5f;
+            d *= 1.0f - kHeuristicMixingValue * wgt;
+            d += wgt * sub[(size_t)p * gs.plane + (size_t)(y / 2) * gs.pitch + x / 2];
+            diffmap[o] = d;
+        }
+        const double dd = d, d3 = dd * dd * dd, d6 = d3 * d3;
+        s3 = d3;
+        s6 = d6;
+        s12 = d6 * d6;
+    }
+    float m = d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m = fmaxf(m, __shfl_down(m, off, 64));
+        s3 += __shfl_down(s3, off, 64);
+        s6 += __shfl_down(s6, off, 64);
+        s12 += __shfl_down(s12, off, 64);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_max[wv] = m;
+        s_sum[0][wv] = s3;
+        s_sum[1][wv] = s6;
+        s_sum[2][wv] = s12;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mm = s_max[0];
+        double a = 0, b = 0, c = 0;
+        for (int k = 0; k < TPB / 64; k++) {
+            mm = fmaxf(mm, s_max[k]);
+            a += s_sum[0][k];
+            b += s_sum[1][k];
+            c += s_sum[2][k];
+        }
+        const size_t bi = (size_t)p * n_blocks + blockIdx.y * gridDim.x + blockIdx.x;
+        blk_max[bi] = mm;
+        blk_sums[bi * 3] = a;
+        blk_sums[bi * 3 + 1] = b;
+        blk_sums[bi * 3 + 2] = c;
+    }
+}
+
+__global__ void k_ba_score(const float *__restrict__ blk_max, const double *__restrict__ blk_sums, ce_dev_scores *__restrict__ scores,
+                           double *__restrict__ pnorm, uint32_t n_pairs, uint32_t n_blocks, uint32_t used_blocks, double npix)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    float mx = 0.0f;
+    double s[3] = {0, 0, 0};
+    for (uint32_t k = 0; k < used_blocks; k++) {
+        mx = fmaxf(mx, blk_max[(size_t)p * n_blocks + k]);
+        for (int q = 0; q < 3; q++) s[q] += blk_sums[((size_t)p * n_blocks + k) * 3 + q];
+    }
+    scores[p].butteraugli = (double)mx;
+    const double opp = 1.0 / npix;
+    pnorm[p] = (pow(opp * s[0], 1.0 / 3.0) + pow(opp * s[1], 1.0 / 6.0) + pow(opp * s[2], 1.0 / 12.0)) / 3.0;
+}
+
+blur_kernel make_kernel(float sigma)
+{
+    blur_kernel bk{};
+    const float m = 2.25f;
+    const double scaler = -1.0 / (2.0 * (double)sigma * (double)sigma);
+    int diff = (int)(m * std::fabs(sigma));
+    if (diff < 1) diff = 1;
+    for (int i = -diff; i <= diff; i++) bk.k[i + diff] = (float)std::exp(scaler * i * i);
+    bk.len = 2 * diff + 1;
+    return bk;
+}
+
+malta_params make_malta(double w_0gt1, double w_0lt1, double norm1, bool lf)
+{
+    const double len = 3.75, mulli = lf ? 0.611612573796 : 0.39905817637;
+    const float kWeight0 = 0.5f, kWeight1 = 0.33f;
+    const double w_pre0gt1 = mulli * std::sqrt(kWeight0 * w_0gt1) / (len * 2 + 1);
+    const double w_pre0lt1 = mulli * std::sqrt(kWeight1 * w_0lt1) / (len * 2 + 1);
+    return malta_params{(float)(w_pre0gt1 * norm1), (float)(w_pre0lt1 * norm1), (float)norm1};
+}
+
+}  // namespace
+
+void ce_butteraugli_free(ce_batch *b)
+{
+    for (int l = 0; l < 2; l++) {
+        hipFree(b->ba_lin[l]);
+        hipFree(b->ba_psy[l]);
+        hipFree(b->ba_diff[l]);
+        b->ba_lin[l] = b->ba_psy[l] = b->ba_diff[l] = nullptr;
+    }
+    for (auto &p : b->ba_s) hipFree(p), p = nullptr;
+    for (auto &p : b->ba_pp) hipFree(p), p = nullptr;
+    hipFree(b->ba_blk_max);
+    hipFree(b->ba_blk_sums);
+    hipFree(b->ba_pnorm);
+    b->ba_blk_max = nullptr;
+    b->ba_blk_sums = nullptr;
+    b->ba_pnorm = nullptr;
+    b->ba_ready = false;
+}
+
+static int ba_prepare(ce_batch *b)
+{
+    if (b->ba_ready) return CE_OK;
+    ce_ctx *ctx = b->ctx;
+    auto set = [](ce_batch::ba_level &d, uint32_t w, uint32_t h) {
+        d.w = w;
+        d.h = h;
+        d.pitch = (w + 31u) & ~31u;
+        d.plane = (size_t)d.pitch * h;
+    };
+    set(b->ba[0], b->w, b->h);
+    set(b->ba[1], (b->w + 1) / 2, (b->h + 1) / 2);
+    b->ba_levels = (b->ba[1].w >= 8 && b->ba[1].h >= 8) ? 2 : 1;
+    const size_t slots = (size_t)b->max_refs + b->max_pairs, P = b->max_pairs, p0 = b->ba[0].plane;
+    for (int l = 0; l < b->ba_levels; l++) {
+        CE_HIP(ctx, hipMalloc(&b->ba_lin[l], slots * 3 * b->ba[l].plane * sizeof(float)));
+        CE_HIP(ctx, hipMalloc(&b->ba_psy[l], slots * PSY * b->ba[l].plane * sizeof(float)));
+        CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));
+    }
+    for (auto &p : b->ba_s) CE_HIP(ctx, hipMalloc(&p, slots * 3 * p0 * sizeof(float)));
+    // pair scratch: 0 diffs, 1 ac[3], 2 dc[3], 3 m0, 4 m1, 5 bl0, 6 bl1, 7 tmp, 8 mask
+    const size_t pp_planes[9] = {1, 3, 3, 1, 1, 1, 1, 1, 1};
+    for (int i = 0; i < 9; i++) CE_HIP(ctx, hipMalloc(&b->ba_pp[i], P * pp_planes[i] * p0 * sizeof(float)));
+    b->ba_blocks = ((b->ba[0].w + 63) / 64) * ((b->ba[0].h + 3) / 4);
+    CE_HIP(ctx, hipMalloc(&b->ba_blk_max, P * b->ba_blocks * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->ba_blk_sums, P * b->ba_blocks * 3 * sizeof(double)));
+    CE_HIP(ctx, hipMalloc(&b->ba_pnorm, P * sizeof(double)));
+    b->ba_ready = true;
+    return CE_OK;
+}
+
+int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs, float intensity_target)
+{
+    ce_ctx *ctx = b->ctx;
+    int rc = ba_prepare(b);
+    if (rc != CE_OK) return rc;
+    const uint32_t n_slots = n_refs_used + n_pairs, mr = b->max_refs, P = b->max_pairs;
+    const blur_kernel k12 = make_kernel(1.2f), kLf = make_kernel(7.15593339443f), kHf = make_kernel(3.22489901262f),
+                      kUhf = make_kernel(1.56416327805f), kMask = make_kernel(2.7f);
+    float sw = 0.0f;
+    for (int j = 0; j < 5; j++) sw += k12.k[j];
+    const float sc = 1.0f / sw, w0 = k12.k[2] * sc, w1 = k12.k[3] * sc, w2 = k12.k[4] * sc;
+    const double hf_asymmetry = 1.0;
+    const malta_params mUhfY = make_malta(1.10039032555 * hf_asymmetry, 1.10039032555 / hf_asymmetry, 71.7800275169, false);
+    const malta_params mUhfX = make_malta(173.5 * hf_asymmetry, 173.5 / hf_asymmetry, 5.0, false);
+    const malta_params mHfY = make_malta(18.7237414387 * std::sqrt(hf_asymmetry), 18.7237414387 / std::sqrt(hf_asymmetry), 4498534.45232, true);
+    const malta_params mHfX = make_malta(6923.99476109 * std::sqrt(hf_asymmetry), 6923.99476109 / std::sqrt(hf_asymmetry), 8051.15833247, true);
+    const malta_params mMfY = make_malta(37.0819870399, 37.0819870399, 130262059.556, true);
+    const malta_params mMfX = make_malta(8246.75321353, 8246.75321353, 1009002.70582, true);
+
+    for (int l = 0; l < b->ba_levels; l++) {
+        const auto &d = b->ba[l];
+        const geom g{d.w, d.h, d.pitch, d.plane};
+        const dim3 gx((d.w + 63) / 64, (d.h + 3) / 4, 1);
+        auto G = [&](uint32_t z) { return dim3(gx.x, gx.y, z); };
+        float *lin = b->ba_lin[l], *psy = b->ba_psy[l], *sA = b->ba_s[0], *sB = b->ba_s[1], *sC = b->ba_s[2];
+        // ---- per image slot: PsychoImage ----
+        if (l == 0) {
+            CE_LAUNCH(ctx, "ba_linear_u8", k_ba_linear_u8, G(n_slots), dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, lin, g,
+                      b->img_bytes, n_refs_used, mr);
+        } else {
+            const auto &pd = b->ba[0];
+            CE_LAUNCH(ctx, "ba_subsample2x", k_ba_subsample2x, G(n_slots * 3), dim3(TPB), 0, b->ba_lin[0], lin,
+                      geom{pd.w, pd.h, pd.pitch, pd.plane}, g, n_refs_used, mr);
+        }
+        const plane_sel s3{3, 0, 3};
+        CE_LAUNCH(ctx, "ba_blur5", k_ba_blur5_mirror<false>, G(n_slots * 3), dim3(TPB), 0, lin, sA, g, s3, s3, w0, w1, w2, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_blur5", k_ba_blur5_mirror<true>, G(n_slots * 3), dim3(TPB), 0, sA, sB, g, s3, s3, w0, w1, w2, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_opsin", k_ba_opsin, G(n_slots), dim3(TPB), 0, lin, sB, sC, g, intensity_target, n_refs_used, mr);  // sC = xyb
+        // LF = blur(xyb, 7.156) -> psy[LF0..2]
+        const plane_sel sLf{PSY, LF0, 3}, sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
+        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_slots * 3), dim3(TPB), 0, sC, sA, g, s3, s3, kLf, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_slots * 3), dim3(TPB), 0, sA, psy, g, s3, sLf, kLf, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_mf_raw", k_ba_mf_raw, G(n_slots * 3), dim3(TPB), 0, sC, psy, g, n_refs_used, mr);
+        // MF = blur(mf_raw, 3.225) -> sB ; split
+        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_slots * 3), dim3(TPB), 0, psy, sA, g, sMf, s3, kHf, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_slots * 3), dim3(TPB), 0, sA, sB, g, s3, s3, kHf, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_split_mf", k_ba_split_mf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
+        // HF = blur(hf_raw, 1.564) -> sB[0..1] ; split
+        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_slots * 2), dim3(TPB), 0, psy, sA, g, sHf, s2, kUhf, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_slots * 2), dim3(TPB), 0, sA, sB, g, s2, s2, kUhf, n_refs_used, mr, 1);
+        CE_LAUNCH(ctx, "ba_split_hf", k_ba_split_hf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
+
+        // ---- per pair ----
+        float *diffs = b->ba_pp[0], *ac = b->ba_pp[1], *dc = b->ba_pp[2], *m0 = b->ba_pp[3], *m1 = b->ba_pp[4],
+              *bl0 = b->ba_pp[5], *bl1 = b->ba_pp[6], *tmp = b->ba_pp[7], *mask = b->ba_pp[8];
+        CE_LAUNCH(ctx, "ba_zero", k_ba_zero, dim3(2048), dim3(TPB), 0, ac, (size_t)P * 3 * b->ba[0].plane);
+        const dim3 mg((d.w + MT - 1) / MT, (d.h + MT - 1) / MT, n_pairs);
+        struct mcall { uint32_t plane_idx; malta_params mp; bool lf; int c; };
+        const mcall calls[6] = {{UHF1, mUhfY, false, 1}, {UHF0, mUhfX, false, 0}, {HF1, mHfY, true, 1},
+                                {HF0, mHfX, true, 0},    {MF1, mMfY, true, 1},    {MF0, mMfX, true, 0}};
+        for (const mcall &mc : calls) {
+            CE_LAUNCH(ctx, "ba_malta_diffs", k_ba_malta_diffs, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, diffs, g, mr,
+                      mc.plane_idx, mc.mp);
+            float *acc = ac + (size_t)mc.c * P * d.plane;
+            if (mc.lf)
+                CE_LAUNCH(ctx, "ba_malta_lf", k_ba_malta<true>, mg, dim3(TPB), 0, diffs, acc, g);
+            else
+                CE_LAUNCH(ctx, "ba_malta_hf", k_ba_malta<false>, mg, dim3(TPB), 0, diffs, acc, g);
+        }
+        CE_LAUNCH(ctx, "ba_l2", k_ba_l2, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P);
+        // mask
+        const plane_sel s1{1, 0, 1};
+        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m0, g, mr, 0);
+        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m1, g, mr, 1);
+        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_pairs), dim3(TPB), 0, m0, tmp, g, s1, s1, kMask, 0u, 0u, 0);
+        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_pairs), dim3(TPB), 0, tmp, bl0, g, s1, s1, kMask, 0u, 0u, 0);
+        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_pairs), dim3(TPB), 0, m1, tmp, g, s1, s1, kMask, 0u, 0u, 0);
+        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_pairs), dim3(TPB), 0, tmp, bl1, g, s1, s1, kMask, 0u, 0u, 0);
+        CE_LAUNCH(ctx, "ba_mask_finish", k_ba_mask_finish, G(n_pairs), dim3(TPB), 0, bl0, bl1, mask, ac + (size_t)1 * P * d.plane, g);
+        CE_LAUNCH(ctx, "ba_combine", k_ba_combine, G(n_pairs), dim3(TPB), 0, mask, ac, dc, b->ba_diff[l], g, P);
+    }
+    const auto &d0 = b->ba[0];
+    const geom g0{d0.w, d0.h, d0.pitch, d0.plane};
+    const bool has_sub = b->ba_levels == 2;
+    const auto &d1 = b->ba[has_sub ? 1 : 0];
+    const geom g1{d1.w, d1.h, d1.pitch, d1.plane};
+    const dim3 gf((d0.w + 63) / 64, (d0.h + 3) / 4, n_pairs);
+    CE_LAUNCH(ctx, "ba_final", k_ba_final, gf, dim3(TPB), 0, b->ba_diff[0], b->ba_diff[has_sub ? 1 : 0], g0, g1, has_sub ? 1 : 0,
+              b->ba_blk_max, b->ba_blk_sums, b->ba_blocks);
+    CE_LAUNCH(ctx, "ba_score", k_ba_score, dim3((n_pairs + 63) / 64), dim3(64), 0, b->ba_blk_max, b->ba_blk_sums, b->d_scores,
+              b->ba_pnorm, n_pairs, b->ba_blocks, gf.x * gf.y, (double)d0.w * (double)d0.h);
+    CE_HIP(ctx, hipGetLastError());
+    return CE_OK;
+}

@@ -235,6 +235,7 @@ void ce_batch_destroy(ce_batch *b)
     hipFree(b->d_partials);
     hipFree(b->d_avg);
     ce_dssim_free(b);
+    ce_butteraugli_free(b);
     delete b;
 }
 
@@ -292,7 +293,6 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     if (n_pairs == 0 || n_pairs > b->max_pairs) return fail(ctx, CE_ERR_INVALID_ARG, "n_pairs out of range");
     const uint32_t known = CE_METRIC_DSSIM | CE_METRIC_SSIMULACRA2 | CE_METRIC_BUTTERAUGLI | CE_METRIC_PSNR;
     if (metric_mask & ~known) return fail(ctx, CE_ERR_INVALID_ARG, "unknown metric bit");
-    (void)intensity_target;
     CE_HIP(ctx, hipSetDevice(ctx->device));
     if (b->pair_ref_dirty) {
         CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, b->h_pair_ref.data(), sizeof(uint32_t) * b->max_pairs,
@@ -323,7 +323,10 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         int rc = ce_launch_dssim(b, d_refs, n_refs_used, n_pairs);
         if (rc != CE_OK) return rc;
     }
-    if (metric_mask & CE_METRIC_BUTTERAUGLI) return fail(ctx, CE_ERR_BACKEND, "Butteraugli kernels are not built yet");
+    if ((metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8) {
+        int rc = ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target);
+        if (rc != CE_OK) return rc;
+    }
     b->last_n_pairs = n_pairs;
     b->last_mask = metric_mask;
     return CE_OK;
@@ -350,6 +353,14 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
             s.dssim = d.dssim;
             s.valid |= CE_METRIC_DSSIM;
         }
+        if (mask & CE_METRIC_BUTTERAUGLI) {
+            if (b->w < 8 || b->h < 8) {  // "minimum 8x8 for butteraugli", src/eval/helpers.rs:89
+                s.status = CE_ERR_TOO_SMALL;
+            } else {
+                s.butteraugli = d.butteraugli;
+                s.valid |= CE_METRIC_BUTTERAUGLI;
+            }
+        }
         if (mask & CE_METRIC_SSIMULACRA2) {
             if (b->w < 8 || b->h < 8) {
                 s.status = CE_ERR_TOO_SMALL;
@@ -360,6 +371,15 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
         }
         out[i] = s;
     }
+    return CE_OK;
+}
+
+int ce_batch_butteraugli_pnorm3(ce_batch *b, uint32_t n_pairs, double *out)
+{
+    if (!b || !out || !b->ba_ready || n_pairs == 0 || n_pairs > b->max_pairs) return CE_ERR_INVALID_ARG;
+    ce_ctx *ctx = b->ctx;
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CE_HIP(ctx, hipMemcpy(out, b->ba_pnorm, sizeof(double) * n_pairs, hipMemcpyDeviceToHost));
     return CE_OK;
 }
 

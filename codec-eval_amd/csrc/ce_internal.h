@@ -105,6 +105,21 @@ struct ce_batch {
     uint32_t ds_blocks = 0;
     bool dssim_ready = false;
 
+    // Butteraugli working set (butteraugli.hip): level 0 = full resolution, 1 = 2x-subsampled
+    struct ba_level { uint32_t w, h, pitch; size_t plane; };
+    ba_level ba[2];
+    int ba_levels = 0;
+    float *ba_lin[2] = {};    // [slot][3][plane_l]
+    float *ba_psy[2] = {};    // [slot][10][plane_l]  PsychoImage
+    float *ba_diff[2] = {};   // [pair][plane_l]      diffmaps
+    float *ba_s[3] = {};      // per-slot scratch, 3 planes each
+    float *ba_pp[9] = {};     // per-pair scratch
+    float *ba_blk_max = nullptr;
+    double *ba_blk_sums = nullptr;
+    double *ba_pnorm = nullptr;  // [pair] libjxl 3-norm of the last run
+    uint32_t ba_blocks = 0;
+    bool ba_ready = false;
+
     uint32_t last_n_pairs = 0;
     uint32_t last_mask = 0;
 };
@@ -136,6 +151,8 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
 int ce_launch_xyb_roundtrip(ce_ctx *ctx, const uint8_t *d_in, uint8_t *d_out, size_t n_pixels);
 int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);
 void ce_dssim_free(ce_batch *b);
+int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs, float intensity_target);
+void ce_butteraugli_free(ce_batch *b);
 int ce_launch_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *d_rgb, float *d_rgba, size_t n_pixels);
 
 // host-side constant builders (ce_tables.cpp)

@@ -155,6 +155,10 @@ int ce_batch_run(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t f
 int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags,
                     float intensity_target);
 int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out);
+/* libjxl's p-norm of the Butteraugli diffmap (mean of the 3-, 6- and 12-norms) for the pairs of the last run
+ * that asked for CE_METRIC_BUTTERAUGLI.  The reference only ever reads `.score` (the max-norm,
+ * src/metrics/butteraugli.rs:80); BASELINE.json's configs[2] also names the 3-norm. */
+int ce_batch_butteraugli_pnorm3(ce_batch *b, uint32_t n_pairs, double *out);
 
 /* ---- reference handle: Ssimulacra2Reference::{new,compare} ------------------------
  * crates/codec-iter/src/eval.rs:138-149,83-89; crates/codec-compare/src/brute_force_sweep.rs:197-201,256 */

@@ -1,0 +1,84 @@
+"""GPU parity: Butteraugli through the C ABI against the CPU oracle (1e-4 relative, north_star).
+Synthetic inputs mirror src/metrics/butteraugli.rs:168-207 and src/eval/helpers.rs:337-383."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+def close(got, want, floor=1e-3):
+    return abs(got - want) <= REL_TOL * max(abs(want), floor)
+
+
+def ramp(w, h):
+    return (np.arange(w * h * 3) % 256).astype(np.uint8)
+
+
+def test_butteraugli_reference_cases(gpu_ctx, oracle, ce):
+    d = ramp(100, 100)
+    assert gpu_ctx.calculate_butteraugli(d, d, 100, 100) < 0.01
+    assert gpu_ctx.calculate_butteraugli_with_intensity(d, d, 100, 100, 250.0) < 0.01
+    r, t = np.full(30000, 100, np.uint8), np.full(30000, 200, np.uint8)
+    got = gpu_ctx.calculate_butteraugli(r, t, 100, 100)
+    assert got > 1.0 and close(got, oracle.butteraugli(r, t, 100, 100)[0])
+    small, large = np.full(50 * 50 * 3, 128, np.uint8), np.full(100 * 100 * 3, 128, np.uint8)
+    with pytest.raises(ce.CodecEvalError):
+        gpu_ctx.calculate_butteraugli(small, large, 100, 100)
+    with pytest.raises(ce.MetricCalculation):  # below 8x8 (src/eval/helpers.rs:89)
+        gpu_ctx.calculate_butteraugli(small[: 7 * 9 * 3], small[: 7 * 9 * 3], 7, 9)
+
+
+SHAPES = [(8, 8), (9, 15), (15, 16), (16, 16), (33, 17), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512)]
+
+
+@pytest.mark.parametrize("w,h", SHAPES)
+def test_butteraugli_parity_shapes(gpu_ctx, oracle, ce, workloads, w, h):
+    ref = workloads.make_reference(w, h, 500 + w)
+    b = ce.Batch(gpu_ctx, w, h, 1, 3)
+    b.set_reference(0, ref)
+    tests = [workloads.distort(ref, q) for q in (30, 75, 95)]
+    for k, t in enumerate(tests):
+        b.set_test(k, 0, t)
+    out = b.run(3, ce.MetricConfig(butteraugli=True))
+    p3 = b.butteraugli_pnorm3(3)
+    b.close()
+    for k, t in enumerate(tests):
+        want, want_p3 = oracle.butteraugli(ref, t, w, h)
+        assert out[k].status == 0 and out[k].valid == ce.METRIC_BUTTERAUGLI
+        assert close(out[k].butteraugli, want), (w, h, k, out[k].butteraugli, want)
+        assert close(p3[k], want_p3), (w, h, k, p3[k], want_p3)
+
+
+def test_butteraugli_intensity_target_and_identity(gpu_ctx, oracle, workloads):
+    w, h = 96, 80
+    ref = workloads.make_reference(w, h, 21)
+    t = workloads.distort(ref, 60)
+    for it in (80.0, 250.0, 30.0):
+        assert close(gpu_ctx.calculate_butteraugli_with_intensity(ref, t, w, h, it), oracle.butteraugli(ref, t, w, h, it)[0])
+    assert gpu_ctx.calculate_butteraugli(ref, ref, w, h) == 0.0
+    noise = workloads.make_reference(w, h, 22, "highfreq")
+    flat = workloads.make_reference(w, h, 23, "flat")
+    for a, b in ((noise, flat), (flat, noise), (np.zeros_like(flat), np.full_like(flat, 255))):
+        assert close(gpu_ctx.calculate_butteraugli(a, b, w, h), oracle.butteraugli(a, b, w, h)[0])
+
+
+def test_all_metrics_one_call(gpu_ctx, oracle, ce, workloads):
+    """MetricConfig::all() and perceptual_xyb() through the dispatcher (session.rs:437-497)."""
+    w, h = 128, 96
+    ref = workloads.make_reference(w, h, 31)
+    t = workloads.distort(ref, 70, True)
+    r = gpu_ctx.calculate_metrics(ref, t, w, h, ce.MetricConfig.all())
+    assert r.psnr == oracle.psnr(ref, t, w, h)
+    assert abs(r.ssimulacra2 - oracle.ssimulacra2(ref, t, w, h, 1)) <= REL_TOL * 100
+    assert close(r.dssim, oracle.dssim(ref, t, w, h), 1e-6)
+    assert close(r.butteraugli, oracle.butteraugli(ref, t, w, h)[0])
+    rx = gpu_ctx.calculate_metrics(ref, t, w, h, ce.MetricConfig.perceptual_xyb())
+    rt = oracle.xyb_roundtrip(ref, w, h)
+    assert rx.psnr is None
+    assert close(rx.butteraugli, oracle.butteraugli(rt, t, w, h)[0])
+    assert close(rx.dssim, oracle.dssim(rt, t, w, h), 1e-6)
+    img = np.stack([(np.arange(64 * 64) % 256)] * 3, -1).astype(np.uint8).reshape(64, 64, 3)
+    res = ce.evaluate_single(gpu_ctx, img, img, ce.MetricConfig.perceptual())  # helpers.rs:337-348
+    assert res.dssim < 0.0001 and res.ssimulacra2 > 99.0 and res.butteraugli < 0.1
