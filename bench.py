@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="6 references instead of 24 (smoke runs)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
+                    help="BASELINE.json configs[] entry, 1-based (default 2 = the headline workload). "
+                         "3/4/5 are extra measurements, scaled down with --refs")
+    ap.add_argument("--refs", type=int, default=0, help="override the number of reference images (configs 3-5)")
     return ap.parse_args()
 
 
@@ -81,8 +85,26 @@ def main():
     # ---- build this rank's shard of the grid (synthetic, seeded) --------------------------------
     qualities = (75, 85, 95)  # codec-iter "quick" preset, crates/codec-iter/src/main.rs:197
     n_land, n_port = (5, 1) if args.quick else (wl.KODAK_LANDSCAPE, wl.KODAK_PORTRAIT)
-    grids = wl.kodak_like(qualities, n_land, n_port, seed0=1000 + 100 * rank)
-    cfg = ce.MetricConfig.ssimulacra2_only()
+    if args.config == 2:
+        grids = wl.kodak_like(qualities, n_land, n_port, seed0=1000 + 100 * rank)
+        cfg = ce.MetricConfig.ssimulacra2_only()
+        workload = ("BASELINE configs[1]: Kodak-24 x 3 quality levels (q75/85/95), SSIMULACRA2 only, "
+                    "768x512 x18 + 512x768 x6 buffers")
+    elif args.config == 3:
+        n = args.refs or 4
+        grids = [wl.uhd_pairs(n, seed0=2000 + 100 * rank)]
+        cfg = ce.MetricConfig(butteraugli=True)
+        workload = f"BASELINE configs[2]: {n} synthetic 3840x2160 pairs, Butteraugli (max-norm + 3-norm)"
+    elif args.config == 4:
+        n = args.refs or 32
+        grids = [wl.cid22_like(n, seed0=3000 + 1000 * rank)]
+        cfg = ce.MetricConfig(ssimulacra2=True, dssim=True)
+        workload = f"BASELINE configs[3]: {n} CID22-shaped 512x512 refs x 8 qualities, SSIMULACRA2 + DSSIM"
+    else:
+        n = args.refs or 15
+        grids = [wl.codec_iter_dense(n, seed0=4000 + 100 * rank)]
+        cfg = ce.MetricConfig.all().with_xyb_roundtrip()
+        workload = f"BASELINE configs[4]: {n} 512x512 refs x 25 qualities x {{4:4:4, 4:2:0}}, all metrics, XYB roundtrip on"
 
     ctx = ce.Context(local_rank)
     batches = []
@@ -116,7 +138,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_mp = mp_per_step * args.steps * world
+    # MP/s = reference pixels x (pair, metric) evaluations / wall time
+    n_metrics = sum(1 for m in ("dssim", "ssimulacra2", "butteraugli", "psnr") if getattr(cfg, m))
+    total_mp = mp_per_step * n_metrics * args.steps * world
     value = total_mp / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -162,7 +186,7 @@ def main():
     # ---- CPU baseline: the C oracle on this host's cores (rank 0, N = 1 only) -------------------
     cpu_baseline = None
     max_dev = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == 2:
         from oracle import oracle as O
 
         O.build()
@@ -214,11 +238,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: Kodak-24 x 3 quality levels (q75/85/95), SSIMULACRA2 only, "
-                            "768x512 x18 + 512x768 x6 buffers" + (" [--quick subset]" if args.quick else ""),
+                "workload": workload + (" [--quick subset]" if args.quick else ""),
                 "pairs_per_gpu_step": pairs_per_step,
                 "megapixels_per_gpu_step": round(mp_per_step, 3),
-                "metrics": ["ssimulacra2"],
+                "metrics": [m for m in ("dssim", "ssimulacra2", "butteraugli", "psnr") if getattr(cfg, m)],
                 "sharding": "by reference image, one process + one HIP stream per GPU, no collective",
                 "inputs": "resident in HBM (uploaded before the timed region)",
             },

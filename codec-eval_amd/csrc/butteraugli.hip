@@ -13,9 +13,8 @@
 //     HF+UHF (blur 2.7, fuzzy erosion), CombineChannelsToDiffmap
 //   then diffmap = 0.85 * full + 0.5 * upsampled(half) ; score = max ; p-norm = mean of 3-, 6-, 12-norms.
 //
-// Long blurs (33 / 15 / 13 / 7 taps, borders re-normalised) read their taps straight from global
-// memory: for a fixed tap the 64 lanes of a wave read 64 consecutive floats, so every request is
-// coalesced and the tap re-reads are L1/L2 hits.  Build with -ffp-contract=off.
+// Long blurs (33 / 15 / 13 / 7 taps, borders re-normalised) are LDS-tiled with a register window
+// (k_ba_blur_h / k_ba_blur_v).  Build with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
 
@@ -122,34 +121,98 @@ __global__ __launch_bounds__(TPB) void k_ba_blur5_mirror(const float *__restrict
     out[((size_t)unit * so.per_unit + so.first + k) * g.plane + o] = r;
 }
 
-template <bool VERT>
-__global__ __launch_bounds__(TPB) void k_ba_blur(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
-                                                 plane_sel so, blur_kernel bk, uint32_t n_refs_used, uint32_t max_refs,
-                                                 int by_slot)
+// Long separable blurs, LDS-tiled with a register window: a thread produces 8 consecutive outputs
+// from 8 + LEN - 1 inputs held in registers (5 LDS reads per output at LEN = 33 instead of 33), each
+// output summing its taps in ascending order exactly like ConvolutionWithTranspose.  Taps outside the
+// image are zero in the tile (x + 0.0f == x, so the sum over the valid taps is unchanged) and border
+// outputs are scaled by 1 / (sum of their valid weights).
+constexpr int BW_OUT = 8;
+
+template <int LEN>
+__device__ __forceinline__ float border_scale(const blur_kernel &bk, int pos, int n, float inv_wsum)
 {
+    constexpr int off = LEN / 2;
+    if (pos - off >= 0 && pos + off <= n - 1) return inv_wsum;
+    float weight = 0.0f;
+    for (int j = max(pos - off, 0); j <= min(pos + off, n - 1); j++) weight += bk.k[j - pos + off];
+    return 1.0f / weight;
+}
+
+// horizontal: block = 8 rows x 256 columns; LDS rows are padded one float per 8 so that lanes reading
+// with a stride of 8 floats hit distinct banks
+template <int LEN>
+__global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
+                                                   plane_sel so, blur_kernel bk, float inv_wsum, uint32_t n_refs_used,
+                                                   uint32_t max_refs, int by_slot)
+{
+    constexpr int off = LEN / 2, TW = 256, TR = 8, RAW = TW + LEN - 1, ROWF = RAW + RAW / 8 + 1;
+    __shared__ float tile[TR * ROWF];
     const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
     const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
-    BA_XY;
     const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
-    const int off = bk.len / 2;
-    const int pos = VERT ? (int)y : (int)x, n = VERT ? (int)g.h : (int)g.w;
-    const int lo = max(pos - off, 0), hi = min(pos + off, n - 1);
-    const float *base = VERT ? p + x : p + (size_t)y * g.pitch;
-    const size_t stride = VERT ? g.pitch : 1;
-    float sum = 0.0f, r;
-    if (lo == pos - off && hi == pos + off) {
-        float wsum = 0.0f;
-        for (int j = 0; j < bk.len; j++) wsum += bk.k[j];
-        for (int j = lo; j <= hi; j++) sum += base[(size_t)j * stride] * bk.k[j - pos + off];
-        r = sum * (1.0f / wsum);
-    } else {
-        float weight = 0.0f;
-        for (int j = lo; j <= hi; j++) weight += bk.k[j - pos + off];
-        const float scale = 1.0f / weight;
-        for (int j = lo; j <= hi; j++) sum += base[(size_t)j * stride] * bk.k[j - pos + off];
-        r = sum * scale;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    for (int i = threadIdx.x; i < TR * RAW; i += TPB) {
+        const int r = i / RAW, c = i % RAW, gx = x0 - off + c, gy = y0 + r;
+        tile[r * ROWF + c + (c >> 3)] = (gx >= 0 && gx < (int)g.w && gy < (int)g.h) ? p[(size_t)gy * g.pitch + gx] : 0.0f;
     }
-    out[((size_t)unit * so.per_unit + so.first + k) * g.plane + o] = r;
+    __syncthreads();
+    const int r = threadIdx.x >> 5, cx = threadIdx.x & 31, gy = y0 + r, gx0 = x0 + 8 * cx;
+    if (gy >= (int)g.h || gx0 >= (int)g.w) return;
+    float v[BW_OUT + LEN - 1];
+#pragma unroll
+    for (int j = 0; j < BW_OUT + LEN - 1; j++) {
+        const int c = 8 * cx + j;
+        v[j] = tile[r * ROWF + c + (c >> 3)];
+    }
+    float *dst = out + ((size_t)unit * so.per_unit + so.first + k) * g.plane + (size_t)gy * g.pitch + gx0;
+    float res[BW_OUT];
+#pragma unroll
+    for (int o = 0; o < BW_OUT; o++) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
+        res[o] = sum * border_scale<LEN>(bk, gx0 + o, (int)g.w, inv_wsum);
+    }
+    if (gx0 + BW_OUT <= (int)g.w) {  // rows are 128-byte aligned and gx0 is a multiple of 8
+        *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+    } else {
+#pragma unroll
+        for (int o = 0; o < BW_OUT; o++)
+            if (gx0 + o < (int)g.w) dst[o] = res[o];
+    }
+}
+
+// vertical: block = 64 columns x 32 rows; lane = column, wave w produces rows 8w .. 8w+7
+template <int LEN>
+__global__ __launch_bounds__(TPB) void k_ba_blur_v(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
+                                                   plane_sel so, blur_kernel bk, float inv_wsum, uint32_t n_refs_used,
+                                                   uint32_t max_refs, int by_slot)
+{
+    constexpr int off = LEN / 2, TW = 64, TR = 32, RAW = TR + LEN - 1;
+    __shared__ float tile[RAW * TW];
+    const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
+    const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
+    const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    for (int i = threadIdx.x; i < RAW * TW; i += TPB) {
+        const int r = i / TW, c = i % TW, gx = x0 + c, gy = y0 - off + r;
+        tile[i] = (gy >= 0 && gy < (int)g.h && gx < (int)g.w) ? p[(size_t)gy * g.pitch + gx] : 0.0f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6, gx = x0 + c, gy0 = y0 + 8 * w;
+    if (gx >= (int)g.w || gy0 >= (int)g.h) return;
+    float v[BW_OUT + LEN - 1];
+#pragma unroll
+    for (int j = 0; j < BW_OUT + LEN - 1; j++) v[j] = tile[(8 * w + j) * TW + c];
+    float *dst = out + ((size_t)unit * so.per_unit + so.first + k) * g.plane + (size_t)gy0 * g.pitch + gx;
+#pragma unroll
+    for (int o = 0; o < BW_OUT; o++) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
+        if (gy0 + o < (int)g.h) dst[(size_t)o * g.pitch] = sum * border_scale<LEN>(bk, gy0 + o, (int)g.h, inv_wsum);
+    }
 }
 
 // ---- OpsinDynamicsImage (pointwise part) ---------------------------------------------------------------
@@ -594,20 +657,35 @@ __global__ __launch_bounds__(TPB) void k_ba_final(float *__restrict__ diffmap, c
     }
 }
 
-__global__ void k_ba_score(const float *__restrict__ blk_max, const double *__restrict__ blk_sums, ce_dev_scores *__restrict__ scores,
-                           double *__restrict__ pnorm, uint32_t n_pairs, uint32_t n_blocks, uint32_t used_blocks, double npix)
+// one block per pair: max and the three power sums over the block partials (fixed order), then the norms
+__global__ __launch_bounds__(TPB) void k_ba_score(const float *__restrict__ blk_max, const double *__restrict__ blk_sums,
+                                                  ce_dev_scores *__restrict__ scores, double *__restrict__ pnorm,
+                                                  uint32_t n_blocks, uint32_t used_blocks, double npix)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
+    __shared__ float s_max[TPB];
+    __shared__ double s_sum[3][TPB];
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
     float mx = 0.0f;
     double s[3] = {0, 0, 0};
-    for (uint32_t k = 0; k < used_blocks; k++) {
+    for (uint32_t k = t; k < used_blocks; k += TPB) {
         mx = fmaxf(mx, blk_max[(size_t)p * n_blocks + k]);
         for (int q = 0; q < 3; q++) s[q] += blk_sums[((size_t)p * n_blocks + k) * 3 + q];
     }
-    scores[p].butteraugli = (double)mx;
-    const double opp = 1.0 / npix;
-    pnorm[p] = (pow(opp * s[0], 1.0 / 3.0) + pow(opp * s[1], 1.0 / 6.0) + pow(opp * s[2], 1.0 / 12.0)) / 3.0;
+    s_max[t] = mx;
+    for (int q = 0; q < 3; q++) s_sum[q][t] = s[q];
+    __syncthreads();
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if ((int)t < off) {
+            s_max[t] = fmaxf(s_max[t], s_max[t + off]);
+            for (int q = 0; q < 3; q++) s_sum[q][t] += s_sum[q][t + off];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        scores[p].butteraugli = (double)s_max[0];
+        const double opp = 1.0 / npix;
+        pnorm[p] = (pow(opp * s_sum[0][0], 1.0 / 3.0) + pow(opp * s_sum[1][0], 1.0 / 6.0) + pow(opp * s_sum[2][0], 1.0 / 12.0)) / 3.0;
+    }
 }
 
 blur_kernel make_kernel(float sigma)
@@ -620,6 +698,38 @@ blur_kernel make_kernel(float sigma)
     for (int i = -diff; i <= diff; i++) bk.k[i + diff] = (float)std::exp(scaler * i * i);
     bk.len = 2 * diff + 1;
     return bk;
+}
+
+float inv_weight_sum(const blur_kernel &bk)
+{
+    float wsum = 0.0f;
+    for (int j = 0; j < bk.len; j++) wsum += bk.k[j];
+    return 1.0f / wsum;
+}
+
+template <int LEN>
+int launch_blur_len(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g, plane_sel si, plane_sel st, plane_sel so,
+                    const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot)
+{
+    const float inv = inv_weight_sum(bk);
+    const dim3 gh((g.w + 255) / 256, (g.h + 7) / 8, units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
+    CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot);
+    CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot);
+    return CE_OK;
+}
+
+// in[si] -> (row pass) tmp[st] -> (column pass) out[so]
+int launch_blur(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g, plane_sel si, plane_sel st, plane_sel so,
+                const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot)
+{
+    switch (bk.len) {
+        case 7: return launch_blur_len<7>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
+        case 13: return launch_blur_len<13>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
+        case 15: return launch_blur_len<15>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
+        case 33: return launch_blur_len<33>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
+    }
+    ctx->err = "unexpected blur kernel length";
+    return CE_ERR_BACKEND;
 }
 
 malta_params make_malta(double w_0gt1, double w_0lt1, double norm1, bool lf)
@@ -723,16 +833,13 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         CE_LAUNCH(ctx, "ba_opsin", k_ba_opsin, G(n_slots), dim3(TPB), 0, lin, sB, sC, g, intensity_target, n_refs_used, mr);  // sC = xyb
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
         const plane_sel sLf{PSY, LF0, 3}, sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
-        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_slots * 3), dim3(TPB), 0, sC, sA, g, s3, s3, kLf, n_refs_used, mr, 1);
-        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_slots * 3), dim3(TPB), 0, sA, psy, g, s3, sLf, kLf, n_refs_used, mr, 1);
+        if ((rc = launch_blur(ctx, sC, sA, psy, g, s3, s3, sLf, kLf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
         CE_LAUNCH(ctx, "ba_mf_raw", k_ba_mf_raw, G(n_slots * 3), dim3(TPB), 0, sC, psy, g, n_refs_used, mr);
         // MF = blur(mf_raw, 3.225) -> sB ; split
-        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_slots * 3), dim3(TPB), 0, psy, sA, g, sMf, s3, kHf, n_refs_used, mr, 1);
-        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_slots * 3), dim3(TPB), 0, sA, sB, g, s3, s3, kHf, n_refs_used, mr, 1);
+        if ((rc = launch_blur(ctx, psy, sA, sB, g, sMf, s3, s3, kHf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
         CE_LAUNCH(ctx, "ba_split_mf", k_ba_split_mf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
         // HF = blur(hf_raw, 1.564) -> sB[0..1] ; split
-        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_slots * 2), dim3(TPB), 0, psy, sA, g, sHf, s2, kUhf, n_refs_used, mr, 1);
-        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_slots * 2), dim3(TPB), 0, sA, sB, g, s2, s2, kUhf, n_refs_used, mr, 1);
+        if ((rc = launch_blur(ctx, psy, sA, sB, g, sHf, s2, s2, kUhf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
         CE_LAUNCH(ctx, "ba_split_hf", k_ba_split_hf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
 
         // ---- per pair ----
@@ -757,10 +864,8 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         const plane_sel s1{1, 0, 1};
         CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m0, g, mr, 0);
         CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m1, g, mr, 1);
-        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_pairs), dim3(TPB), 0, m0, tmp, g, s1, s1, kMask, 0u, 0u, 0);
-        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_pairs), dim3(TPB), 0, tmp, bl0, g, s1, s1, kMask, 0u, 0u, 0);
-        CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur<false>, G(n_pairs), dim3(TPB), 0, m1, tmp, g, s1, s1, kMask, 0u, 0u, 0);
-        CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur<true>, G(n_pairs), dim3(TPB), 0, tmp, bl1, g, s1, s1, kMask, 0u, 0u, 0);
+        if ((rc = launch_blur(ctx, m0, tmp, bl0, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
+        if ((rc = launch_blur(ctx, m1, tmp, bl1, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
         CE_LAUNCH(ctx, "ba_mask_finish", k_ba_mask_finish, G(n_pairs), dim3(TPB), 0, bl0, bl1, mask, ac + (size_t)1 * P * d.plane, g);
         CE_LAUNCH(ctx, "ba_combine", k_ba_combine, G(n_pairs), dim3(TPB), 0, mask, ac, dc, b->ba_diff[l], g, P);
     }
@@ -772,8 +877,8 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     const dim3 gf((d0.w + 63) / 64, (d0.h + 3) / 4, n_pairs);
     CE_LAUNCH(ctx, "ba_final", k_ba_final, gf, dim3(TPB), 0, b->ba_diff[0], b->ba_diff[has_sub ? 1 : 0], g0, g1, has_sub ? 1 : 0,
               b->ba_blk_max, b->ba_blk_sums, b->ba_blocks);
-    CE_LAUNCH(ctx, "ba_score", k_ba_score, dim3((n_pairs + 63) / 64), dim3(64), 0, b->ba_blk_max, b->ba_blk_sums, b->d_scores,
-              b->ba_pnorm, n_pairs, b->ba_blocks, gf.x * gf.y, (double)d0.w * (double)d0.h);
+    CE_LAUNCH(ctx, "ba_score", k_ba_score, dim3(n_pairs), dim3(TPB), 0, b->ba_blk_max, b->ba_blk_sums, b->d_scores, b->ba_pnorm,
+              b->ba_blocks, gf.x * gf.y, (double)d0.w * (double)d0.h);
     CE_HIP(ctx, hipGetLastError());
     return CE_OK;
 }

@@ -192,24 +192,38 @@ __global__ __launch_bounds__(TPB) void k_dssim_ssim_map(const float *__restrict_
         part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
-// ---- mean absolute deviation from avg = max(mean, 0)^(0.5^level) ---------------------------------------
-__global__ __launch_bounds__(TPB) void k_dssim_absdev(const float *__restrict__ map, double *__restrict__ part, uint32_t w,
-                                                      uint32_t h, uint32_t pitch, size_t plane, uint32_t level,
-                                                      uint32_t n_levels, uint32_t n_blocks, uint32_t used_blocks)
+// ---- avg = max(mean, 0)^(0.5^level): one block per pair reduces the SSIM partial sums in a fixed order ----
+__global__ __launch_bounds__(TPB) void k_dssim_avg(const double *__restrict__ part, double *__restrict__ avg_out, uint32_t w,
+                                                   uint32_t h, uint32_t level, uint32_t n_levels, uint32_t n_blocks,
+                                                   uint32_t used_blocks)
+{
+    __shared__ double s_red[TPB];
+    const uint32_t p = blockIdx.x;
+    const double *pp = part + ((size_t)p * n_levels + level) * 2 * n_blocks;
+    double v = 0.0;
+    for (uint32_t k = threadIdx.x; k < used_blocks; k += TPB) v += pp[k];
+    s_red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = TPB / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double avg = s_red[0] / (double)((size_t)w * h);
+        if (!(avg > 0.0)) avg = 0.0;
+        avg_out[(size_t)p * n_levels + level] = pow(avg, pow(0.5, (double)level));
+    }
+}
+
+// ---- mean absolute deviation of the SSIM map from avg ------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_dssim_absdev(const float *__restrict__ map, const double *__restrict__ avg_in,
+                                                      double *__restrict__ part, uint32_t w, uint32_t h, uint32_t pitch,
+                                                      size_t plane, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
 {
     __shared__ double s_red[TPB / 64];
-    __shared__ double s_avg;
     const uint32_t p = blockIdx.z;
     double *pp = part + ((size_t)p * n_levels + level) * 2 * n_blocks;
-    if (threadIdx.x == 0) {
-        double sum = 0.0;
-        for (uint32_t k = 0; k < used_blocks; k++) sum += pp[k];  // fixed order: deterministic
-        double avg = sum / (double)((size_t)w * h);
-        if (!(avg > 0.0)) avg = 0.0;
-        s_avg = pow(avg, pow(0.5, (double)level));
-    }
-    __syncthreads();
-    const double avg = s_avg;
+    const double avg = avg_in[(size_t)p * n_levels + level];
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     double val = 0.0;
     if (x < w && y < h) val = fabs(avg - (double)map[(size_t)p * plane + (size_t)y * pitch + x]);
@@ -289,7 +303,7 @@ static int dssim_prepare(ce_batch *b)
     CE_HIP(ctx, hipMalloc(&b->ds_map, (size_t)b->max_pairs * p0 * sizeof(float)));
     b->ds_blocks = ((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
-    CE_HIP(ctx, hipMalloc(&b->ds_level_scores, (size_t)b->max_pairs * CE_DSSIM_SCALES * sizeof(double)));
+    CE_HIP(ctx, hipMalloc(&b->ds_level_scores, (size_t)b->max_pairs * CE_DSSIM_SCALES * sizeof(double)));  // avg, then score
     b->dssim_ready = true;
     return CE_OK;
 }
@@ -341,8 +355,10 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         const uint32_t used_blocks = grid.x * grid.y;
         CE_LAUNCH(ctx, "dssim_ssim_map", k_dssim_ssim_map, gp, dim3(TPB), 0, b->ds_mu, b->ds_sq, b->ds_i12, b->d_pair_ref, b->ds_map,
                   b->ds_part, d.w, d.h, d.pitch, d.plane, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
-        CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, b->ds_map, b->ds_part, d.w, d.h, d.pitch, d.plane,
-                  (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, used_blocks);
+        CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
+                  (uint32_t)b->ds_levels, b->ds_blocks, used_blocks);
+        CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, b->ds_map, b->ds_level_scores, b->ds_part, d.w, d.h,
+                  d.pitch, d.plane, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         g.npix[l] = d.w * d.h;
         g.nblk[l] = used_blocks;
     }
