@@ -680,8 +680,11 @@ int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float 
     const float *src = nullptr;
     // d_xyb and d_hbuf hold only the LAST level processed; the caller asks for that level
     switch (which) {
-        case 0: src = b->d_lin[scale] + (size_t)ref_slot * 3 * d.plane; break;
-        case 1: src = b->d_lin[scale] + (size_t)test_slot * 3 * d.plane; break;
+        case 0:
+        case 1:
+            if (scale == 0) return CE_ERR_INVALID_ARG;  // level 0 has no linear plane (read from u8 on the fly)
+            src = b->d_lin[scale] + (size_t)(which == 0 ? ref_slot : test_slot) * 3 * d.plane;
+            break;
         case 2: src = b->d_xyb + (size_t)ref_slot * 3 * d.plane; break;
         case 3: src = b->d_xyb + (size_t)test_slot * 3 * d.plane; break;
         case 4:

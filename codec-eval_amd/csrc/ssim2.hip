@@ -26,58 +26,11 @@ struct rg_consts {
     float mul_prev[3];
 };
 
-constexpr int kRowsPerBlock = 64;
 constexpr int kColsPerBlock = 64;
 
 __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, uint32_t max_refs)
 {
     return z < n_refs_used ? z : max_refs + (z - n_refs_used);
-}
-
-// ---- level 0: sRGB u8 (interleaved) -> linear f32 planes -------------------------------
-__global__ __launch_bounds__(256) void k_ssim2_linear_u8(const uint8_t *__restrict__ refs,
-                                                         const uint8_t *__restrict__ tests,
-                                                         const float *__restrict__ lut, float *__restrict__ lin,
-                                                         uint32_t w, uint32_t h, uint32_t pitch, size_t plane,
-                                                         size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
-{
-    __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
-    const uint32_t z = blockIdx.z;
-    const uint32_t slot = slot_of(z, n_refs_used, max_refs);
-    const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
-    float *dst = lin + (size_t)slot * 3 * plane;
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const uint8_t *px = src + ((size_t)y * w + x) * 3;
-    const size_t o = (size_t)y * pitch + x;
-    dst[o] = s_lut[px[0]];
-    dst[plane + o] = s_lut[px[1]];
-    dst[2 * plane + o] = s_lut[px[2]];
-}
-
-// ---- level s -> s+1: 2x2 box average of linear RGB, edge-clamped, ceil sizes -------------
-__global__ __launch_bounds__(256) void k_ssim2_downscale(const float *__restrict__ in, float *__restrict__ out,
-                                                         uint32_t iw, uint32_t ih, uint32_t ipitch, size_t iplane,
-                                                         uint32_t ow, uint32_t oh, uint32_t opitch, size_t oplane,
-                                                         uint32_t n_refs_used, uint32_t max_refs)
-{
-    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs);
-    const uint32_t c = blockIdx.z % 3;
-    const uint32_t ox = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ox >= ow || oy >= oh) return;
-    const float *ip = in + ((size_t)slot * 3 + c) * iplane;
-    const uint32_t x0 = ox * 2, y0 = oy * 2;
-    const uint32_t x1 = min(x0 + 1, iw - 1), y1 = min(y0 + 1, ih - 1);
-    float sum = 0.0f;
-    sum += ip[(size_t)y0 * ipitch + x0];
-    sum += ip[(size_t)y0 * ipitch + x1];
-    sum += ip[(size_t)y1 * ipitch + x0];
-    sum += ip[(size_t)y1 * ipitch + x1];
-    out[((size_t)slot * 3 + c) * oplane + (size_t)oy * opitch + ox] = sum * 0.25f;
 }
 
 // ---- linear RGB -> positive XYB -----------------------------------------------------------
@@ -132,21 +85,68 @@ __device__ __forceinline__ void linear_to_xyb_positive(float r, float g, float b
     Y = Y + 0.01f;
 }
 
-__global__ __launch_bounds__(256) void k_ssim2_xyb(const float *__restrict__ lin, float *__restrict__ xyb, uint32_t w,
-                                                   uint32_t h, uint32_t pitch, size_t plane, uint32_t n_refs_used,
-                                                   uint32_t max_refs)
+// ---- per-level front end, one 2x2 quad per thread ------------------------------------------------
+// Reads the level's linear RGB (level 0: sRGB u8 through the 256-entry table, no linear plane is ever
+// materialised at full resolution), writes the level's positive-XYB planes and the NEXT level's
+// linear RGB (2x2 box average, edge-clamped, ceil sizes; summed in the lineage's (y, x) order).
+template <bool FROM_U8>
+__global__ __launch_bounds__(256) void k_ssim2_prep(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
+                                                    const float *__restrict__ lut, const float *__restrict__ lin_in,
+                                                    float *__restrict__ xyb, float *__restrict__ lin_out, uint32_t w,
+                                                    uint32_t h, uint32_t pitch, size_t plane, uint32_t opitch,
+                                                    size_t oplane, int has_next, size_t img_bytes, uint32_t n_refs_used,
+                                                    uint32_t max_refs)
 {
-    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const size_t o = (size_t)slot * 3 * plane + (size_t)y * pitch + x;
+    __shared__ float s_lut[256];
+    if (FROM_U8) {
+        s_lut[threadIdx.x] = lut[threadIdx.x];
+        __syncthreads();
+    }
+    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const uint32_t qx = blockIdx.x * 64 + (threadIdx.x & 63), qy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (qx >= (w + 1) / 2 || qy >= (h + 1) / 2) return;
+    const uint8_t *src8 = nullptr;
+    if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
+    const float *srcf = lin_in + (size_t)slot * 3 * plane;
     const float cbrt_bias = cbrt_f32(K_B0);
-    float X, Y, B;
-    linear_to_xyb_positive(lin[o], lin[o + plane], lin[o + 2 * plane], cbrt_bias, X, Y, B);
-    xyb[o] = X;
-    xyb[o + plane] = Y;
-    xyb[o + 2 * plane] = B;
+    float sum[3] = {0.0f, 0.0f, 0.0f};
+    float *xo = xyb + (size_t)slot * 3 * plane;
+#pragma unroll
+    for (uint32_t dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (uint32_t dx = 0; dx < 2; dx++) {
+            const uint32_t xr = 2 * qx + dx, yr = 2 * qy + dy;
+            const uint32_t x = min(xr, w - 1), y = min(yr, h - 1);
+            float r, g, bl;
+            if (FROM_U8) {
+                const uint8_t *px = src8 + ((size_t)y * w + x) * 3;
+                r = s_lut[px[0]];
+                g = s_lut[px[1]];
+                bl = s_lut[px[2]];
+            } else {
+                const size_t o = (size_t)y * pitch + x;
+                r = srcf[o];
+                g = srcf[o + plane];
+                bl = srcf[o + 2 * plane];
+            }
+            sum[0] += r;
+            sum[1] += g;
+            sum[2] += bl;
+            if (xr < w && yr < h) {
+                float X, Y, B;
+                linear_to_xyb_positive(r, g, bl, cbrt_bias, X, Y, B);
+                const size_t o = (size_t)y * pitch + x;
+                xo[o] = X;
+                xo[o + plane] = Y;
+                xo[o + 2 * plane] = B;
+            }
+        }
+    if (has_next) {
+        float *lo = lin_out + (size_t)slot * 3 * oplane + (size_t)qy * opitch + qx;
+        lo[0] = sum[0] * 0.25f;
+        lo[oplane] = sum[1] * 0.25f;
+        lo[2 * oplane] = sum[2] * 0.25f;
+    }
 }
 
 // one step of the three second-order sections for one stream; returns the filter output
@@ -163,63 +163,6 @@ __device__ __forceinline__ float rg_step(float sum, float (&prev)[3], float (&pr
         o[k] = v;
     }
     return o[0] + o[1] + o[2];
-}
-
-// ---- row pass: one thread per (row, channel, pair), all five streams -------------------
-// Input step i consumes in[i] (right tap, n+N-1) and in[i-10] (left tap, n-N-1) and emits
-// output n = i-4.  Four steps per iteration so loads and stores are 16-byte.
-__global__ __launch_bounds__(kRowsPerBlock) void k_ssim2_hblur(const float *__restrict__ xyb,
-                                                               const uint32_t *__restrict__ pair_ref,
-                                                               float *__restrict__ hbuf, uint32_t w, uint32_t h,
-                                                               uint32_t pitch, size_t plane, uint32_t max_refs,
-                                                               rg_consts rg)
-{
-    const uint32_t y = blockIdx.x * kRowsPerBlock + threadIdx.x;
-    if (y >= h) return;
-    const uint32_t c = blockIdx.y, p = blockIdx.z;
-    const float *a = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + (size_t)y * pitch;
-    const float *b = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + (size_t)y * pitch;
-    float *o = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + (size_t)y * pitch;
-
-    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3];
-#pragma unroll
-    for (int s = 0; s < CE_SSIM2_STREAMS; s++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) prev[s][k] = prev2[s][k] = 0.0f;
-
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 am1 = zero4, am2 = zero4, am3 = zero4, bm1 = zero4, bm2 = zero4, bm3 = zero4;
-    const uint32_t nj = (w + 4 + 3) / 4;
-    for (uint32_t j = 0; j < nj; j++) {
-        const uint32_t i0 = 4 * j;
-        float4 a0 = zero4, b0 = zero4;
-        if (i0 < w) {
-            a0 = *reinterpret_cast<const float4 *>(a + i0);
-            b0 = *reinterpret_cast<const float4 *>(b + i0);
-            if (i0 + 1 >= w) a0.y = b0.y = 0.0f;
-            if (i0 + 2 >= w) a0.z = b0.z = 0.0f;
-            if (i0 + 3 >= w) a0.w = b0.w = 0.0f;
-        }
-        const float ra[4] = {a0.x, a0.y, a0.z, a0.w}, rb[4] = {b0.x, b0.y, b0.z, b0.w};
-        const float la[4] = {am3.z, am3.w, am2.x, am2.y}, lb[4] = {bm3.z, bm3.w, bm2.x, bm2.y};
-        float out[CE_SSIM2_STREAMS][4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            out[0][e] = rg_step(la[e] + ra[e], prev[0], prev2[0], rg);
-            out[1][e] = rg_step(lb[e] + rb[e], prev[1], prev2[1], rg);
-            out[2][e] = rg_step(la[e] * la[e] + ra[e] * ra[e], prev[2], prev2[2], rg);
-            out[3][e] = rg_step(lb[e] * lb[e] + rb[e] * rb[e], prev[3], prev2[3], rg);
-            out[4][e] = rg_step(la[e] * lb[e] + ra[e] * rb[e], prev[4], prev2[4], rg);
-        }
-        if (j >= 1) {
-#pragma unroll
-            for (int s = 0; s < CE_SSIM2_STREAMS; s++)
-                *reinterpret_cast<float4 *>(o + (size_t)s * plane + (i0 - 4)) =
-                    make_float4(out[s][0], out[s][1], out[s][2], out[s][3]);
-        }
-        am3 = am2; am2 = am1; am1 = a0;
-        bm3 = bm2; bm2 = bm1; bm1 = b0;
-    }
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
@@ -385,84 +328,7 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// ---- column pass + SSIM/edge maps + pooling: one thread per (column, channel, pair) ----
-__global__ __launch_bounds__(kColsPerBlock) void k_ssim2_vblur_ssim(const float *__restrict__ hbuf,
-                                                                    const float *__restrict__ xyb,
-                                                                    const uint32_t *__restrict__ pair_ref,
-                                                                    double *__restrict__ partials, uint32_t w,
-                                                                    uint32_t h, uint32_t pitch, size_t plane,
-                                                                    uint32_t hpitch, size_t hplane,
-                                                                    uint32_t max_refs, uint32_t scale,
-                                                                    uint32_t max_vblocks, rg_consts rg)
-{
-    const uint32_t xr = blockIdx.x * kColsPerBlock + threadIdx.x;
-    const bool active = xr < w;
-    const uint32_t x = active ? xr : w - 1;
-    const uint32_t c = blockIdx.y, p = blockIdx.z;
-    const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * hplane + x;
-    const float *xa = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + x;
-    const float *xb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + x;
-
-    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3], ring[10][CE_SSIM2_STREAMS];
-#pragma unroll
-    for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) prev[s][k] = prev2[s][k] = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 10; e++) ring[e][s] = 0.0f;
-    }
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const float C2 = 0.0009f;
-    const uint32_t steps = h + 4;
-    for (uint32_t i0 = 0; i0 < steps; i0 += 10) {
-#pragma unroll
-        for (int e = 0; e < 10; e++) {
-            const uint32_t i = i0 + e;
-            if (i < steps) {
-                float v[CE_SSIM2_STREAMS];
-#pragma unroll
-                for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
-                    const float right = i < h ? hb[(size_t)s * hplane + (size_t)i * hpitch] : 0.0f;
-                    const float left = ring[e][s];
-                    ring[e][s] = right;
-                    v[s] = rg_step(left + right, prev[s], prev2[s], rg);
-                }
-                if (i >= 4) {
-                    const uint32_t n = i - 4;
-                    const float img1 = xa[(size_t)n * pitch], img2 = xb[(size_t)n * pitch];
-                    const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
-                    const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
-                    const float mu_diff = mu1 - mu2;
-                    const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
-                    const float num_s = __builtin_fmaf(2.0f, s12 - mu12, C2);
-                    const float denom_s = (s11 - mu11) + (s22 - mu22) + C2;
-                    double d = 1.0 - (double)((num_m * num_s) / denom_s);
-                    if (!(d > 0.0)) d = 0.0;
-                    acc[0] += d;
-                    const double d2 = d * d;
-                    acc[1] += d2 * d2;
-                    const double d1 = (1.0 + (double)fabsf(img2 - mu2)) / (1.0 + (double)fabsf(img1 - mu1)) - 1.0;
-                    const double artifact = d1 > 0.0 ? d1 : 0.0;
-                    const double detail = -d1 > 0.0 ? -d1 : 0.0;
-                    acc[2] += artifact;
-                    const double a2 = artifact * artifact;
-                    acc[3] += a2 * a2;
-                    acc[4] += detail;
-                    const double l2 = detail * detail;
-                    acc[5] += l2 * l2;
-                }
-            }
-        }
-    }
-    double *dst = partials + ((((size_t)p * CE_MAX_SCALES + scale) * 3 + c) * max_vblocks + blockIdx.x) * 6;
-#pragma unroll
-    for (int q = 0; q < 6; q++) {
-        const double s = wave_sum(active ? acc[q] : 0.0);
-        if (threadIdx.x == 0) dst[q] = s;
-    }
-}
-
-// ---- column pass v2: LDS-DMA ring, one wave per 64-column strip -----------------------------
+// ---- column pass + SSIM/edge maps + pooling: LDS-DMA ring, one wave per 64-column strip -----------------------------
 // Thread = column, all five streams (15 independent recurrences per lane).  The five row-blurred
 // planes and the two XYB planes arrive by LDS-DMA (global_load_lds_dwordx4: one instruction moves
 // 4 rows x 64 columns, no VGPRs) into a wave-private 2-group ring; group g+2 is requested as soon
@@ -530,6 +396,7 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
                 // group g has landed once at most the 7 requests of group g+1 are outstanding
                 asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
                 const float *slot = ring + (gg & 1) * VB_GROUP + lane;
+                float gacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < VB_G; e++) {
                     const uint32_t i = (uint32_t)(4 * g + e);
@@ -553,22 +420,28 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
                         const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
                         const float num_s = __builtin_fmaf(2.0f, s12 - mu12, C2);
                         const float denom_s = (s11 - mu11) + (s22 - mu22) + C2;
-                        double d = 1.0 - (double)((num_m * num_s) / denom_s);
-                        if (!(d > 0.0)) d = 0.0;
-                        acc[0] += d;
-                        const double d2 = d * d;
-                        acc[1] += d2 * d2;
-                        const double d1 = (1.0 + (double)fabsf(img2 - mu2)) / (1.0 + (double)fabsf(img1 - mu1)) - 1.0;
-                        const double artifact = d1 > 0.0 ? d1 : 0.0;
-                        const double detail = -d1 > 0.0 ? -d1 : 0.0;
-                        acc[2] += artifact;
-                        const double a2 = artifact * artifact;
-                        acc[3] += a2 * a2;
-                        acc[4] += detail;
-                        const double l2 = detail * detail;
-                        acc[5] += l2 * l2;
+                        // The lineage widens here and pools in f64.  On the device the per-pixel terms stay
+                        // f32 (1 - ratio is exact for ratio in [0.5, 2]; the edge ratio is formed as
+                        // (|e2| - |e1|) / (1 + |e1|), relative error ~2e-7 instead of an f64 divide), are summed
+                        // in f32 over the 4 rows of a DMA group and only then added to the f64 accumulators.
+                        float d = 1.0f - (num_m * num_s) / denom_s;
+                        d = d > 0.0f ? d : 0.0f;
+                        const float dd = d * d;
+                        const float e1 = fabsf(img1 - mu1), e2 = fabsf(img2 - mu2);
+                        const float d1 = (e2 - e1) / (1.0f + e1);
+                        const float artifact = d1 > 0.0f ? d1 : 0.0f;
+                        const float detail = d1 < 0.0f ? -d1 : 0.0f;
+                        const float aa = artifact * artifact, ll = detail * detail;
+                        gacc[0] += d;
+                        gacc[1] += dd * dd;
+                        gacc[2] += artifact;
+                        gacc[3] += aa * aa;
+                        gacc[4] += detail;
+                        gacc[5] += ll * ll;
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < 6; q++) acc[q] += (double)gacc[q];
                 // this group's slot is free once its LDS reads have returned; refill it with group g+2
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 issue_group(g + 2);
@@ -673,7 +546,7 @@ int ce_ssim2_prepare(ce_batch *b)
     b->n_scales = ns;
     if (ns == 0) return CE_OK;
     const size_t slots = (size_t)b->max_refs + b->max_pairs;
-    for (int s = 0; s < ns; s++)
+    for (int s = 1; s < ns; s++)  // level 0 is read straight from the u8 slabs
         CE_HIP(ctx, hipMalloc(&b->d_lin[s], slots * 3 * b->sd[s].plane * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->d_xyb, slots * 3 * b->sd[0].plane * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->d_hbuf, (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[0].hplane * sizeof(float)));
@@ -708,19 +581,17 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     const int levels = std::min(b->n_scales, b->debug_max_scales);
     for (int s = 0; s < levels; s++) {
         const ce_scale_dims &d = b->sd[s];
-        const dim3 pix_grid((d.w + 63) / 64, (d.h + 3) / 4, n_slots);
-        if (s == 0) {
-            CE_LAUNCH(ctx, "ssim2_linear_u8", k_ssim2_linear_u8, pix_grid, dim3(256), 0, d_refs, b->d_tests,
-                      ctx->d_lut_ssim2, b->d_lin[0], d.w, d.h, d.pitch, d.plane, b->img_bytes, n_refs_used,
-                      b->max_refs);
-        } else {
-            const ce_scale_dims &pd = b->sd[s - 1];
-            CE_LAUNCH(ctx, "ssim2_downscale", k_ssim2_downscale, dim3(pix_grid.x, pix_grid.y, n_slots * 3), dim3(256),
-                      0, b->d_lin[s - 1], b->d_lin[s], pd.w, pd.h, pd.pitch, pd.plane, d.w, d.h, d.pitch, d.plane,
-                      n_refs_used, b->max_refs);
-        }
-        CE_LAUNCH(ctx, "ssim2_xyb", k_ssim2_xyb, pix_grid, dim3(256), 0, b->d_lin[s], b->d_xyb, d.w, d.h, d.pitch,
-                  d.plane, n_refs_used, b->max_refs);
+        const bool has_next = s + 1 < levels;
+        const ce_scale_dims &nd = b->sd[has_next ? s + 1 : s];
+        const dim3 quad_grid(((d.w + 1) / 2 + 63) / 64, ((d.h + 1) / 2 + 3) / 4, n_slots);
+        if (s == 0)
+            CE_LAUNCH(ctx, "ssim2_prep_u8", k_ssim2_prep<true>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
+                      (const float *)nullptr, b->d_xyb, b->d_lin[1], d.w, d.h, d.pitch, d.plane, nd.pitch, nd.plane,
+                      has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
+        else
+            CE_LAUNCH(ctx, "ssim2_prep", k_ssim2_prep<false>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
+                      (const float *)b->d_lin[s], b->d_xyb, b->d_lin[has_next ? s + 1 : s], d.w, d.h, d.pitch, d.plane,
+                      nd.pitch, nd.plane, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
         CE_LAUNCH(ctx, kHName[s], kHblur[s], dim3((d.h + HB_ROWS - 1) / HB_ROWS, 3, n_pairs), dim3(HB_THREADS), 0,
                   b->d_xyb, b->d_pair_ref, b->d_hbuf, d.w, d.h, d.pitch, d.plane, b->max_refs, rg);
         const uint32_t nblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
