@@ -161,11 +161,13 @@ def main():
         avg_s = ms / launches * 1e-3
         bytes_per_launch = SSIM2_PASS_BYTES_L0 * px0 / n_launch_per_step
         achieved = bytes_per_launch / avg_s / 1e9
-        traffic = None
+        traffic = None  # HBM bytes per launch from the PMC counters (profiles/traffic_r01.json, separate --pmc passes)
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(name)
+                rec = json.load(f).get(name)
+            if rec:
+                traffic = rec["bytes_per_scale0_pixel"] * px0 / n_launch_per_step
         roofline = {
             "bound": "hbm",
             "kernel": name,
