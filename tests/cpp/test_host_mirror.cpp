@@ -1,0 +1,178 @@
+// Exercises the C++ host mirror (codec-eval_amd/host/codec_eval.hpp) the way the reference's own unit
+// tests exercise the Rust API (src/metrics/*.rs, src/eval/{session,helpers}.rs #[cfg(test)]).
+// usage: test_host_mirror [cpu|gpu]   — "cpu" runs only what needs no device.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "codec_eval.hpp"
+
+using namespace codec_eval;
+using eval::ImageData;
+
+static int g_fail = 0;
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #c);    \
+            g_fail++;                                                   \
+        }                                                               \
+    } while (0)
+
+// src/eval/helpers.rs:327-335
+static ImageData create_test_image(size_t w, size_t h, uint8_t pattern)
+{
+    std::vector<uint8_t> d(w * h * 3);
+    for (size_t i = 0; i < w * h; i++) {
+        const size_t base = (i + pattern) % 256;
+        d[3 * i] = (uint8_t)base;
+        d[3 * i + 1] = (uint8_t)(base + 50);
+        d[3 * i + 2] = (uint8_t)(base + 100);
+    }
+    return ImageData::rgb(std::move(d), w, h);
+}
+
+static void host_only()
+{
+    // src/metrics/mod.rs:338-397
+    CHECK(perception_from_dssim(0.0001) == PerceptionLevel::Imperceptible);
+    CHECK(perception_from_dssim(0.0003) == PerceptionLevel::Marginal);
+    CHECK(perception_from_dssim(0.0007) == PerceptionLevel::Subtle);
+    CHECK(perception_from_dssim(0.0015) == PerceptionLevel::Noticeable);
+    CHECK(perception_from_dssim(0.003) == PerceptionLevel::Degraded);
+    CHECK(perception_from_ssimulacra2(90.5) == PerceptionLevel::Imperceptible);
+    CHECK(perception_from_butteraugli(4.9) == PerceptionLevel::Noticeable);
+    CHECK(MetricConfig::all().dssim && MetricConfig::all().psnr && MetricConfig::all().mask() == 15u);
+    CHECK(!MetricConfig::fast().dssim && MetricConfig::fast().psnr);
+    CHECK(MetricConfig::perceptual_xyb().flags() == CE_FLAG_XYB_ROUNDTRIP);
+    CHECK(std::strcmp(perception_code(PerceptionLevel::Subtle), "SUB") == 0);
+    // src/eval/session.rs:600-637
+    ImageData img = create_test_image(100, 50, 0);
+    CHECK(img.width == 100 && img.height == 50 && img.to_rgb8_vec().size() == 100 * 50 * 3);
+    ImageData rgba = ImageData::rgba(std::vector<uint8_t>{1, 2, 3, 255, 4, 5, 6, 128}, 2, 1);
+    CHECK((rgba.to_rgb8_vec() == std::vector<uint8_t>{1, 2, 3, 4, 5, 6}));
+    eval::EvalConfig cfg;
+    CHECK(cfg.quality_levels.size() == 7 && cfg.quality_levels.front() == 50.0 && cfg.quality_levels.back() == 95.0);
+    if (HipBackend::device_count() <= 0) {  // no device: creation must fail loudly, never fall back
+        bool threw = false;
+        try {
+            HipBackend be(0);
+        } catch (const Error &e) {
+            threw = e.kind == Error::Kind::MetricCalculation;
+        }
+        CHECK(threw);
+    }
+}
+
+static void with_gpu()
+{
+    auto be = std::make_shared<HipBackend>(0);
+    // src/metrics/mod.rs:368-383
+    std::vector<uint8_t> same(100 * 100 * 3, 128), r(100 * 100 * 3, 100), t(100 * 100 * 3, 110);
+    CHECK(std::isinf(metrics::calculate_psnr(*be, same, same, 100, 100)));
+    const double p = metrics::calculate_psnr(*be, r, t, 100, 100);
+    CHECK(p == 10.0 * std::log10(255.0 * 255.0 / 100.0));
+    bool panicked = false;
+    try {
+        metrics::calculate_psnr(*be, same, std::vector<uint8_t>(30), 100, 100);
+    } catch (const std::logic_error &) {
+        panicked = true;
+    }
+    CHECK(panicked);
+    // src/metrics/ssimulacra2.rs:153-182, butteraugli.rs:168-207
+    std::vector<uint8_t> ramp(100 * 100 * 3);
+    for (size_t i = 0; i < ramp.size(); i++) ramp[i] = (uint8_t)(i % 256);
+    CHECK(metrics::calculate_ssimulacra2(*be, ramp, ramp, 100, 100) > 99.0);
+    CHECK(metrics::calculate_butteraugli(*be, ramp, ramp, 100, 100) < 0.01);
+    CHECK(metrics::calculate_butteraugli_with_intensity(*be, ramp, ramp, 100, 100, 250.0f) < 0.01);
+    std::vector<uint8_t> g100(100 * 100 * 3, 100), g200(100 * 100 * 3, 200);
+    CHECK(metrics::calculate_ssimulacra2(*be, g100, g200, 100, 100) < 80.0);
+    CHECK(metrics::calculate_butteraugli(*be, g100, g200, 100, 100) > 1.0);
+    CHECK(metrics::calculate_dssim(*be, g100, g200, 100, 100) > 0.0);
+    bool mismatch = false;
+    try {
+        metrics::calculate_ssimulacra2(*be, std::vector<uint8_t>(50 * 50 * 3, 128), same, 100, 100);
+    } catch (const Error &e) {
+        mismatch = e.kind == Error::Kind::DimensionMismatch;
+    }
+    CHECK(mismatch);
+    // src/metrics/xyb.rs:259-272, dssim.rs:252-262
+    std::vector<uint8_t> rgb(64 * 64 * 3);
+    for (size_t i = 0; i < rgb.size(); i++) rgb[i] = (uint8_t)(i % 256);
+    CHECK(metrics::xyb_roundtrip(*be, rgb, 64, 64).size() == rgb.size());
+    CHECK(metrics::xyb_roundtrip(*be, rgb, 64, 64) == metrics::xyb_roundtrip(*be, rgb, 64, 64));
+    const auto lin = metrics::rgb8_to_dssim_image(*be, {255, 0, 0, 0, 255, 0}, 2, 1);
+    CHECK(std::fabs(lin[0] - 1.0f) < 0.001f && std::fabs(lin[5] - 1.0f) < 0.001f && lin[3] == 1.0f);
+
+    // src/eval/helpers.rs:337-383
+    const ImageData img = create_test_image(64, 64, 0), shifted = create_test_image(64, 64, 50);
+    const MetricResult res = eval::evaluate_single(*be, img, img, MetricConfig::perceptual());
+    CHECK(*res.dssim < 0.0001 && *res.ssimulacra2 > 99.0 && *res.butteraugli < 0.1 && !res.psnr);
+    bool dm = false;
+    try {
+        eval::evaluate_single(*be, img, create_test_image(32, 32, 0), MetricConfig::perceptual());
+    } catch (const Error &e) {
+        dm = e.kind == Error::Kind::DimensionMismatch;
+    }
+    CHECK(dm);
+    eval::assert_quality(*be, img, img, 90.0, 0.001);
+    bool below = false;
+    try {
+        eval::assert_quality(*be, img, shifted, 99.0, std::nullopt);
+    } catch (const Error &e) {
+        below = e.kind == Error::Kind::QualityBelowThreshold;
+    }
+    CHECK(below);
+    eval::assert_perception_level(*be, img, img, PerceptionLevel::Imperceptible);
+
+    // EvalSession::evaluate_image with a toy codec: "encode" keeps the pixels, "decode" quantises them with a
+    // step that shrinks as quality grows.  The whole codec x quality grid is scored by one batch call and must
+    // equal the per-pair leaf calls, in the reference's loop order (session.rs:375-410).
+    eval::EvalConfig cfg;
+    cfg.metrics = MetricConfig::all();
+    cfg.quality_levels = {50.0, 75.0, 95.0};
+    eval::EvalSession session(be, cfg);
+    int current_step = 1;
+    auto encode = [&](const ImageData &im, const eval::EncodeRequest &rq) {
+        current_step = 1 + (int)((100.0 - rq.quality) / 8.0);
+        return im.to_rgb8_vec();
+    };
+    auto decode = [&](const std::vector<uint8_t> &bytes) {
+        std::vector<uint8_t> d(bytes);
+        for (auto &v : d) v = (uint8_t)std::min(255, (v / current_step) * current_step + current_step / 2);
+        return ImageData::rgb(std::move(d), 96, 80);
+    };
+    session.add_codec_with_decode("toy-a", "1.0", encode, decode);
+    session.add_codec("size-only", "0.1", encode);
+    CHECK(session.codec_count() == 2);
+    const ImageData src = create_test_image(96, 80, 7);
+    const eval::ImageReport rep = session.evaluate_image("pattern.png", src);
+    CHECK(rep.results.size() == 6 && rep.width == 96 && rep.height == 80);
+    for (size_t i = 0; i < 3; i++) {
+        const eval::CodecResult &cr = rep.results[i];
+        CHECK(cr.codec_id == "toy-a" && cr.quality == cfg.quality_levels[i] && cr.decode_time.has_value());
+        CHECK(cr.file_size == 96 * 80 * 3 && cr.bits_per_pixel == 24.0);
+        current_step = 1 + (int)((100.0 - cr.quality) / 8.0);
+        const ImageData dec = decode(src.to_rgb8_vec());
+        const auto a = src.to_rgb8_vec(), b = dec.to_rgb8_vec();
+        CHECK(*cr.metrics.psnr == metrics::calculate_psnr(*be, a, b, 96, 80));
+        CHECK(*cr.metrics.ssimulacra2 == metrics::calculate_ssimulacra2(*be, a, b, 96, 80));
+        CHECK(*cr.metrics.dssim == metrics::calculate_dssim(*be, a, b, 96, 80));
+        CHECK(*cr.metrics.butteraugli == metrics::calculate_butteraugli(*be, a, b, 96, 80));
+        CHECK(cr.perception == cr.metrics.perception_level());
+    }
+    CHECK(*rep.results[0].metrics.ssimulacra2 < *rep.results[2].metrics.ssimulacra2);  // quality 50 < quality 95
+    for (size_t i = 3; i < 6; i++) {  // no decoder: size only (session.rs:411-428)
+        CHECK(rep.results[i].codec_id == "size-only" && !rep.results[i].metrics.psnr && !rep.results[i].perception);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    host_only();
+    if (gpu) with_gpu();
+    std::printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", g_fail);
+    return g_fail ? 1 : 0;
+}
