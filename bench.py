@@ -106,10 +106,12 @@ def main():
         cfg = ce.MetricConfig.all().with_xyb_roundtrip()
         workload = f"BASELINE configs[4]: {n} 512x512 refs x 25 qualities x {{4:4:4, 4:2:0}}, all metrics, XYB roundtrip on"
 
-    ctx = ce.Context(local_rank)
+    # one context (= one HIP stream family) per shape bucket, so the buckets' kernel chains overlap on the GPU
+    ctxs = [ce.Context(local_rank) for _ in grids]
+    ctx = ctxs[0]
     batches = []
-    for g in grids:
-        b = ce.Batch(ctx, g.width, g.height, len(g.references), len(g.pairs))
+    for g, c in zip(grids, ctxs):
+        b = ce.Batch(c, g.width, g.height, len(g.references), len(g.pairs))
         for i, r in enumerate(g.references):
             b.set_reference(i, r)
         for k, (ri, t) in enumerate(g.pairs):
@@ -148,12 +150,19 @@ def main():
     roofline = None
     kernels = {}
     if rank == 0:
-        ctx.prof_reset()
-        ctx.prof_enable(True)
+        for c in ctxs:
+            c.prof_reset()
+            c.prof_enable(True)
         for _ in range(args.steps):
-            step()
-        ctx.prof_enable(False)
-        kernels = ctx.prof_stats()
+            for g, b in batches:  # one bucket at a time and one stream each: kernel times must not overlap
+                b.launch(len(g.pairs), cfg)
+                b.collect(len(g.pairs))
+        kernels = {}
+        for c in ctxs:
+            c.prof_enable(False)
+            for k, (n, ms) in c.prof_stats().items():
+                n0, ms0 = kernels.get(k, (0, 0.0))
+                kernels[k] = (n0 + n, ms0 + ms)
         total_ms = sum(ms for _, ms in kernels.values())
         name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
         px0 = sum(len(g.pairs) * g.width * g.height for g in grids)  # scale-0 pixels per step
@@ -180,9 +189,11 @@ def main():
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": launches,
             "kernel_share_of_gpu_time": round(ms / total_ms, 3),
-            # the whole metric against the same peak: 210 B per scale-0 pixel
-            "pipeline_achieved": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 * args.steps / (total_ms * 1e-3) / 1e9, 1),
-            "pipeline_frac": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 * args.steps / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            # the whole metric against the same peak: 210 B per scale-0 pixel over the TIMED
+            # step (levels and shape buckets overlap on separate streams there, so this is not the kernel sum)
+            "pipeline_achieved": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9, 1),
+            "pipeline_frac": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "serial_kernel_ms_per_step": round(total_ms / args.steps, 4),
         }
 
     # ---- CPU baseline: the C oracle on this host's cores (rank 0, N = 1 only) -------------------
@@ -256,7 +267,8 @@ def main():
 
     for _, b in batches:
         b.close()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

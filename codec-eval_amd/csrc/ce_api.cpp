@@ -45,7 +45,7 @@ double psnr_from_sse(unsigned long long sse, size_t w, size_t h)
 
 // ---- profiling -----------------------------------------------------------------------------
 
-int ce_prof_begin(ce_ctx *ctx, const char *name)
+int ce_prof_begin(ce_ctx *ctx, const char *name, hipStream_t stream)
 {
     int idx = -1;
     for (size_t i = 0; i < ctx->stats.size(); i++)
@@ -63,12 +63,12 @@ int ce_prof_begin(ce_ctx *ctx, const char *name)
             return -1;
         }
     }
-    hipEventRecord(pd.e0, ctx->stream);
+    hipEventRecord(pd.e0, stream);
     ctx->pend.push_back(pd);
     return (int)ctx->pend.size() - 1;
 }
 
-void ce_prof_end(ce_ctx *ctx, int token) { hipEventRecord(ctx->pend[token].e1, ctx->stream); }
+void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream) { hipEventRecord(ctx->pend[token].e1, stream); }
 
 static void prof_drain(ce_ctx *ctx)
 {
@@ -230,8 +230,13 @@ void ce_batch_destroy(ce_batch *b)
     if (b->h_scores) hipHostFree(b->h_scores);
     if (b->h_stage) hipHostFree(b->h_stage);
     for (auto &p : b->d_lin) hipFree(p);
-    hipFree(b->d_xyb);
-    hipFree(b->d_hbuf);
+    for (int l = 0; l < CE_MAX_SCALES; l++) {
+        hipFree(b->d_xyb[l]);
+        hipFree(b->d_hbuf[l]);
+        if (b->lvl_stream[l]) hipStreamSynchronize(b->lvl_stream[l]), hipStreamDestroy(b->lvl_stream[l]);
+        if (b->ev_prep[l]) hipEventDestroy(b->ev_prep[l]);
+        if (b->ev_done[l]) hipEventDestroy(b->ev_done[l]);
+    }
     hipFree(b->d_partials);
     hipFree(b->d_avg);
     ce_dssim_free(b);
@@ -678,18 +683,17 @@ int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float 
     if (out_floats < (size_t)nplanes * d.w * d.h) return CE_ERR_INVALID_ARG;
     const uint32_t ref_slot = b->h_pair_ref[0], test_slot = b->max_refs;
     const float *src = nullptr;
-    // d_xyb and d_hbuf hold only the LAST level processed; the caller asks for that level
     switch (which) {
         case 0:
         case 1:
             if (scale == 0) return CE_ERR_INVALID_ARG;  // level 0 has no linear plane (read from u8 on the fly)
             src = b->d_lin[scale] + (size_t)(which == 0 ? ref_slot : test_slot) * 3 * d.plane;
             break;
-        case 2: src = b->d_xyb + (size_t)ref_slot * 3 * d.plane; break;
-        case 3: src = b->d_xyb + (size_t)test_slot * 3 * d.plane; break;
+        case 2: src = b->d_xyb[scale] + (size_t)ref_slot * 3 * d.plane; break;
+        case 3: src = b->d_xyb[scale] + (size_t)test_slot * 3 * d.plane; break;
         case 4:
             if (channel < 0 || channel > 2) return CE_ERR_INVALID_ARG;
-            src = b->d_hbuf + (size_t)channel * CE_SSIM2_STREAMS * d.hplane;
+            src = b->d_hbuf[scale] + (size_t)channel * CE_SSIM2_STREAMS * d.hplane;
             break;
         default: return CE_ERR_INVALID_ARG;
     }

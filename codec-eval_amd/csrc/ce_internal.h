@@ -79,8 +79,12 @@ struct ce_batch {
     int n_scales = 0;
     ce_scale_dims sd[CE_MAX_SCALES];
     float *d_lin[CE_MAX_SCALES] = {};  // [slots][3][plane_s] linear RGB pyramid
-    float *d_xyb = nullptr;            // [slots][3][plane_0]  (reused per scale)
-    float *d_hbuf = nullptr;           // [pairs][3][5][plane_0] row-blurred streams
+    float *d_xyb[CE_MAX_SCALES] = {};   // [slots][3][plane_s] positive XYB, one buffer per level
+    float *d_hbuf[CE_MAX_SCALES] = {};  // [pairs][3][5][plane_s] row-blurred streams, one buffer per level
+    // the levels' row/column passes are independent once the front end has produced the level's XYB:
+    // each level runs on its own stream, fenced by events against the front end and the final reduction
+    hipStream_t lvl_stream[CE_MAX_SCALES] = {};
+    hipEvent_t ev_prep[CE_MAX_SCALES] = {}, ev_done[CE_MAX_SCALES] = {};
     double *d_partials = nullptr;      // [pairs][scales][3][max_blocks][6]
     uint32_t max_vblocks = 0;
     double *d_avg = nullptr;           // [pairs][6][3][6]
@@ -134,15 +138,17 @@ struct ce_batch {
     } while (0)
 
 // profiling hooks around a launch (ce_api.cpp)
-int ce_prof_begin(ce_ctx *ctx, const char *name);
-void ce_prof_end(ce_ctx *ctx, int token);
+int ce_prof_begin(ce_ctx *ctx, const char *name, hipStream_t stream);
+void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream);
 
-#define CE_LAUNCH(ctx_, name_, kern_, grid_, block_, shmem_, ...)                                  \
+#define CE_LAUNCH_ON(ctx_, stream_, name_, kern_, grid_, block_, shmem_, ...)                      \
     do {                                                                                           \
-        int tok__ = (ctx_)->prof ? ce_prof_begin((ctx_), name_) : -1;                              \
-        hipLaunchKernelGGL(kern_, grid_, block_, shmem_, (ctx_)->stream, __VA_ARGS__);             \
-        if (tok__ >= 0) ce_prof_end((ctx_), tok__);                                                \
+        int tok__ = (ctx_)->prof ? ce_prof_begin((ctx_), name_, (stream_)) : -1;                   \
+        hipLaunchKernelGGL(kern_, grid_, block_, shmem_, (stream_), __VA_ARGS__);                  \
+        if (tok__ >= 0) ce_prof_end((ctx_), tok__, (stream_));                                     \
     } while (0)
+#define CE_LAUNCH(ctx_, name_, kern_, grid_, block_, shmem_, ...)                                  \
+    CE_LAUNCH_ON(ctx_, (ctx_)->stream, name_, kern_, grid_, block_, shmem_, __VA_ARGS__)
 
 // ---- kernel launchers (one .hip file per metric) ---------------------------------------
 int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);

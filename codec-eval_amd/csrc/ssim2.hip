@@ -548,8 +548,13 @@ int ce_ssim2_prepare(ce_batch *b)
     const size_t slots = (size_t)b->max_refs + b->max_pairs;
     for (int s = 1; s < ns; s++)  // level 0 is read straight from the u8 slabs
         CE_HIP(ctx, hipMalloc(&b->d_lin[s], slots * 3 * b->sd[s].plane * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->d_xyb, slots * 3 * b->sd[0].plane * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->d_hbuf, (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[0].hplane * sizeof(float)));
+    for (int s = 0; s < ns; s++) {
+        CE_HIP(ctx, hipMalloc(&b->d_xyb[s], slots * 3 * b->sd[s].plane * sizeof(float)));
+        CE_HIP(ctx, hipMalloc(&b->d_hbuf[s], (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[s].plane * sizeof(float)));
+        CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[s], hipStreamNonBlocking));
+        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_prep[s], hipEventDisableTiming));
+        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
+    }
     b->max_vblocks = (b->sd[0].w + kColsPerBlock - 1) / kColsPerBlock;
     CE_HIP(ctx, hipMalloc(&b->d_partials, (size_t)b->max_pairs * CE_MAX_SCALES * 3 * b->max_vblocks * 6 * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->d_avg, (size_t)b->max_pairs * CE_MAX_SCALES * 18 * sizeof(double)));
@@ -579,6 +584,9 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                                                    k_ssim2_vblur_dma<3>, k_ssim2_vblur_dma<4>, k_ssim2_vblur_dma<5>};
     scale_geom g{};
     const int levels = std::min(b->n_scales, b->debug_max_scales);
+    // Front end on the context's stream (level s+1 needs level s's linear planes); each level's row and
+    // column pass on that level's own stream, so the small, latency-bound levels overlap the large ones.
+    // Under profiling everything stays on one stream so that per-kernel times do not overlap.
     for (int s = 0; s < levels; s++) {
         const ce_scale_dims &d = b->sd[s];
         const bool has_next = s + 1 < levels;
@@ -586,21 +594,28 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         const dim3 quad_grid(((d.w + 1) / 2 + 63) / 64, ((d.h + 1) / 2 + 3) / 4, n_slots);
         if (s == 0)
             CE_LAUNCH(ctx, "ssim2_prep_u8", k_ssim2_prep<true>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
-                      (const float *)nullptr, b->d_xyb, b->d_lin[1], d.w, d.h, d.pitch, d.plane, nd.pitch, nd.plane,
+                      (const float *)nullptr, b->d_xyb[0], b->d_lin[1], d.w, d.h, d.pitch, d.plane, nd.pitch, nd.plane,
                       has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
         else
             CE_LAUNCH(ctx, "ssim2_prep", k_ssim2_prep<false>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
-                      (const float *)b->d_lin[s], b->d_xyb, b->d_lin[has_next ? s + 1 : s], d.w, d.h, d.pitch, d.plane,
+                      (const float *)b->d_lin[s], b->d_xyb[s], b->d_lin[has_next ? s + 1 : s], d.w, d.h, d.pitch, d.plane,
                       nd.pitch, nd.plane, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
-        CE_LAUNCH(ctx, kHName[s], kHblur[s], dim3((d.h + HB_ROWS - 1) / HB_ROWS, 3, n_pairs), dim3(HB_THREADS), 0,
-                  b->d_xyb, b->d_pair_ref, b->d_hbuf, d.w, d.h, d.pitch, d.plane, b->max_refs, rg);
+        hipStream_t ls = ctx->prof ? ctx->stream : b->lvl_stream[s];
+        if (ls != ctx->stream) {
+            CE_HIP(ctx, hipEventRecord(b->ev_prep[s], ctx->stream));
+            CE_HIP(ctx, hipStreamWaitEvent(ls, b->ev_prep[s], 0));
+        }
+        CE_LAUNCH_ON(ctx, ls, kHName[s], kHblur[s], dim3((d.h + HB_ROWS - 1) / HB_ROWS, 3, n_pairs), dim3(HB_THREADS), 0,
+                     b->d_xyb[s], b->d_pair_ref, b->d_hbuf[s], d.w, d.h, d.pitch, d.plane, b->max_refs, rg);
         const uint32_t nblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
-        CE_LAUNCH(ctx, kVName[s], kVblur[s], dim3(nblk, 3, n_pairs), dim3(64), 0, b->d_hbuf, b->d_xyb, b->d_pair_ref,
-                  b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs,
-                  (uint32_t)s, b->max_vblocks, rg);
+        CE_LAUNCH_ON(ctx, ls, kVName[s], kVblur[s], dim3(nblk, 3, n_pairs), dim3(64), 0, b->d_hbuf[s], b->d_xyb[s],
+                     b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, (uint32_t)s, b->max_vblocks, rg);
+        if (ls != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[s], ls));
         g.npix[s] = d.w * d.h;
         g.nblk[s] = nblk;
     }
+    if (!ctx->prof)
+        for (int s = 0; s < levels; s++) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[s], 0));
     CE_LAUNCH(ctx, "ssim2_finalize", k_ssim2_finalize, dim3(n_pairs), dim3(128), 0, b->d_partials, b->d_avg,
               b->d_scores, (uint32_t)levels, b->max_vblocks, g);
     CE_HIP(ctx, hipGetLastError());
