@@ -22,26 +22,6 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, ui
     return z < n_refs_used ? z : max_refs + (z - n_refs_used);
 }
 
-// ---- level 0: sRGB u8 -> linear f32 planes through the host-powf table (dssim.rs:78-85) ----------
-__global__ __launch_bounds__(TPB) void k_dssim_linear_u8(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
-                                                         const float *__restrict__ lut, float *__restrict__ lin, uint32_t w,
-                                                         uint32_t h, uint32_t pitch, size_t plane, size_t img_bytes,
-                                                         uint32_t n_refs_used, uint32_t max_refs)
-{
-    __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
-    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
-    const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const uint8_t *px = src + ((size_t)y * w + x) * 3;
-    float *dst = lin + (size_t)slot * 3 * plane + (size_t)y * pitch + x;
-    dst[0] = s_lut[px[0]];
-    dst[plane] = s_lut[px[1]];
-    dst[2 * plane] = s_lut[px[2]];
-}
-
 // ---- rgb8_to_dssim_image (dssim.rs:102-114): interleaved RGBA f32, a = 1.0 -------------------------
 __global__ __launch_bounds__(TPB) void k_rgb8_to_rgba_f32(const uint8_t *__restrict__ rgb, const float *__restrict__ lut,
                                                           float4 *__restrict__ out, size_t n)
@@ -51,20 +31,6 @@ __global__ __launch_bounds__(TPB) void k_rgb8_to_rgba_f32(const uint8_t *__restr
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB)
         out[i] = make_float4(s_lut[rgb[3 * i]], s_lut[rgb[3 * i + 1]], s_lut[rgb[3 * i + 2]], 1.0f);
-}
-
-// ---- Downsample: (a + b + c + d) * 0.25, floor sizes, odd last row/column dropped --------------------
-__global__ __launch_bounds__(TPB) void k_dssim_downsample(const float *__restrict__ in, float *__restrict__ out, uint32_t ipitch,
-                                                          size_t iplane, uint32_t ow, uint32_t oh, uint32_t opitch,
-                                                          size_t oplane, uint32_t n_refs_used, uint32_t max_refs)
-{
-    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs), c = blockIdx.z % 3;
-    const uint32_t ox = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ox >= ow || oy >= oh) return;
-    const float *p = in + ((size_t)slot * 3 + c) * iplane;
-    const float a = p[(size_t)(2 * oy) * ipitch + 2 * ox], b = p[(size_t)(2 * oy) * ipitch + 2 * ox + 1];
-    const float cc = p[(size_t)(2 * oy + 1) * ipitch + 2 * ox], d = p[(size_t)(2 * oy + 1) * ipitch + 2 * ox + 1];
-    out[((size_t)slot * 3 + c) * oplane + (size_t)oy * opitch + ox] = (a + b + cc + d) * 0.25f;
 }
 
 // ---- linear RGB -> normalised (L, a, b) ------------------------------------------------------------
@@ -78,14 +44,8 @@ __device__ __forceinline__ float cbrt_poly(float x)
     return y;
 }
 
-__global__ __launch_bounds__(TPB) void k_dssim_lab(const float *__restrict__ lin, float *__restrict__ lab, uint32_t w, uint32_t h,
-                                                   uint32_t pitch, size_t plane, uint32_t n_refs_used, uint32_t max_refs)
+__device__ __forceinline__ void rgb_to_lab(float r, float g, float b, float &L, float &A, float &B)
 {
-    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const size_t o = (size_t)slot * 3 * plane + (size_t)y * pitch + x;
-    const float r = lin[o], g = lin[o + plane], b = lin[o + 2 * plane];
     const float D65X = 0.9505f, D65Y = 1.0f, D65Z = 1.089f;
     const float EPS = 216.0f / 24389.0f, K = 24389.0f / (27.0f * 116.0f);
     const float fx = __builtin_fmaf(b, 0.1805f / D65X, __builtin_fmaf(g, 0.3576f / D65X, r * (0.4124f / D65X)));
@@ -94,50 +54,140 @@ __global__ __launch_bounds__(TPB) void k_dssim_lab(const float *__restrict__ lin
     const float X = fx > EPS ? cbrt_poly(fx) - 16.0f / 116.0f : K * fx;
     const float Y = fy > EPS ? cbrt_poly(fy) - 16.0f / 116.0f : K * fy;
     const float Z = fz > EPS ? cbrt_poly(fz) - 16.0f / 116.0f : K * fz;
-    lab[o] = Y * 1.05f;
-    lab[o + plane] = __builtin_fmaf(500.0f / 220.0f, X - Y, 86.2f / 220.0f);
-    lab[o + 2 * plane] = __builtin_fmaf(200.0f / 220.0f, Y - Z, 107.9f / 220.0f);
+    L = Y * 1.05f;
+    A = __builtin_fmaf(500.0f / 220.0f, X - Y, 86.2f / 220.0f);
+    B = __builtin_fmaf(200.0f / 220.0f, Y - Z, 107.9f / 220.0f);
 }
 
-// ---- one 3x3 pass with edge replication over n planes ------------------------------------------------
-// MODE 0: in ; MODE 1: in*in ; MODE 2: in*in2 (products formed per tap, i.e. "blur of the product image").
-// planes are addressed as base + (zslot * planes_per_slot + first_plane + k) * plane
-template <int MODE>
-__global__ __launch_bounds__(TPB) void k_blur3x3(const float *__restrict__ in, const float *__restrict__ in2,
-                                                 float *__restrict__ out, uint32_t w, uint32_t h, uint32_t pitch, size_t plane,
-                                                 uint32_t n_planes, uint32_t in_pps, uint32_t in_first, uint32_t out_pps,
-                                                 uint32_t out_first, const uint32_t *__restrict__ in_slot_map,
-                                                 const uint32_t *__restrict__ in2_slot_map, uint32_t in2_slot_base,
-                                                 uint32_t n_refs_used, uint32_t max_refs, int out_by_z)
+// One 3x3 pass with edge replication, evaluated on an LDS region of width RW whose local (0,0) is global
+// (gx0, gy0).  The centre (lx, ly) must be inside the image; neighbours are clamped in GLOBAL coordinates,
+// which is exactly "replicate the edge of that pass's input".  SQ squares every tap (blur of the squared
+// image).  Summation order as in oracle/dssim.c: corners, edges, centre.
+template <int RW, bool SQ>
+__device__ __forceinline__ float pass3x3(const float *__restrict__ A, int lx, int ly, int gx0, int gy0, int w, int h)
 {
-    const uint32_t z = blockIdx.z / n_planes, k = blockIdx.z % n_planes;
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    // slot selection: image-slot passes enumerate used slots; pair passes map pair -> (ref slot, test slot)
-    uint32_t s_in, s_in2 = 0, s_out;
-    if (in_slot_map) {
-        s_in = in_slot_map[z];
-        s_in2 = in2_slot_base + z;
-        s_out = z;
-    } else {
-        s_in = out_by_z ? z : slot_of(z, n_refs_used, max_refs);
-        s_out = s_in;
-    }
-    (void)in2_slot_map;
-    const float *p = in + ((size_t)s_in * in_pps + in_first + k) * plane;
-    const float *q = MODE == 2 ? in2 + ((size_t)s_in2 * in_pps + in_first + k) * plane : nullptr;
-    const uint32_t y0 = y > 0 ? y - 1 : 0, y2 = y + 1 < h ? y + 1 : y;
-    const uint32_t c0 = x > 0 ? x - 1 : 0, c2 = x + 1 < w ? x + 1 : w - 1;
-    auto at = [&](uint32_t yy, uint32_t xx) {
-        const float v = p[(size_t)yy * pitch + xx];
-        if (MODE == 0) return v;
-        if (MODE == 1) return v * v;
-        return v * q[(size_t)yy * pitch + xx];
+    const int X = gx0 + lx, Y = gy0 + ly;
+    const int xm = max(X - 1, 0) - gx0, xp = min(X + 1, w - 1) - gx0;
+    const int ym = max(Y - 1, 0) - gy0, yp = min(Y + 1, h - 1) - gy0;
+    auto at = [&](int yy, int xx) {
+        const float v = A[yy * RW + xx];
+        return SQ ? v * v : v;
     };
     const float K0 = 0.095332f, K1 = 0.118095f, K4 = 0.146293f;
-    const float r = (at(y0, c0) + at(y0, c2) + at(y2, c0) + at(y2, c2)) * K0 +
-                    (at(y0, x) + at(y, c0) + at(y, c2) + at(y2, x)) * K1 + at(y, x) * K4;
-    out[((size_t)s_out * out_pps + out_first + k) * plane + (size_t)y * pitch + x] = r;
+    return (at(ym, xm) + at(ym, xp) + at(yp, xm) + at(yp, xp)) * K0 + (at(ym, lx) + at(ly, xm) + at(ly, xp) + at(yp, lx)) * K1 +
+           at(ly, lx) * K4;
+}
+
+struct lvl_geom {
+    uint32_t w, h, pitch;
+    size_t plane;
+};
+
+// ---- Dssim::create_image for one level, fused: 32x32 tile + halo 4 in LDS ------------------------------------
+// linear RGB (level 0: sRGB u8 through the host-powf table) -> L*a*b* -> chroma pre-blur (2 passes) ->
+// mu = blur(img) (2 passes), sq = blur(img*img) (2 passes); also the next level's linear RGB.
+// Writes img, mu, sq (9 planes) for the tile; every intermediate lives in LDS only.
+constexpr int DT = 32, DR = DT + 8;
+template <bool FROM_U8>
+__global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
+                                                      const float *__restrict__ lut, const float *__restrict__ lin_in,
+                                                      float *__restrict__ lin_out, float *__restrict__ img, float *__restrict__ mu,
+                                                      float *__restrict__ sq, lvl_geom g, lvl_geom gn, int has_next,
+                                                      size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+{
+    __shared__ float P[9][DR * DR];
+    __shared__ float s_lut[256];
+    if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
+    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const int w = (int)g.w, h = (int)g.h;
+    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 4, gy0 = y0 - 4;
+    const uint8_t *src8 = nullptr;
+    if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
+    const float *srcf = lin_in + (size_t)slot * 3 * g.plane;
+    __syncthreads();
+    auto load_rgb = [&](int X, int Y, float &r, float &gg, float &b) {
+        if (FROM_U8) {
+            const uint8_t *px = src8 + ((size_t)Y * w + X) * 3;
+            r = s_lut[px[0]];
+            gg = s_lut[px[1]];
+            b = s_lut[px[2]];
+        } else {
+            const size_t o = (size_t)Y * g.pitch + X;
+            r = srcf[o];
+            gg = srcf[o + g.plane];
+            b = srcf[o + 2 * g.plane];
+        }
+    };
+    // S0: L*a*b* of the clamped region
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
+        float r, gg, b;
+        load_rgb(X, Y, r, gg, b);
+        rgb_to_lab(r, gg, b, P[0][i], P[1][i], P[2][i]);
+    }
+    // next level: (a + b + c + d) * 0.25 over the tile's own 2x2 quads, floor sizes (odd last row/column dropped)
+    if (has_next) {
+        const int ox = x0 / 2 + (threadIdx.x & 15), oy = y0 / 2 + (threadIdx.x >> 4);
+        if (ox < (int)gn.w && oy < (int)gn.h) {
+            float q[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) load_rgb(2 * ox + (k & 1), 2 * oy + (k >> 1), q[k][0], q[k][1], q[k][2]);
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                lin_out[((size_t)slot * 3 + c) * gn.plane + (size_t)oy * gn.pitch + ox] = (q[0][c] + q[1][c] + q[2][c] + q[3][c]) * 0.25f;
+        }
+    }
+    __syncthreads();
+    auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
+    // S1: chroma pre-blur pass 1 (margin 1): P1,P2 -> P3,P4
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 1 && lx < DR - 1 && ly >= 1 && ly < DR - 1 && inside(lx, ly)) {
+            P[3][i] = pass3x3<DR, false>(P[1], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<DR, false>(P[2], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S2: chroma pre-blur pass 2 (margin 2): P3,P4 -> P5,P6 ; img = (P0, P5, P6)
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 2 && lx < DR - 2 && ly >= 2 && ly < DR - 2 && inside(lx, ly)) {
+            P[5][i] = pass3x3<DR, false>(P[3], lx, ly, gx0, gy0, w, h);
+            P[6][i] = pass3x3<DR, false>(P[4], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S3: first pass of mu and sq (margin 3): img -> P1,P2,P3 (mu) and P4,P7,P8 (sq)
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 3 && lx < DR - 3 && ly >= 3 && ly < DR - 3 && inside(lx, ly)) {
+            P[1][i] = pass3x3<DR, false>(P[0], lx, ly, gx0, gy0, w, h);
+            P[2][i] = pass3x3<DR, false>(P[5], lx, ly, gx0, gy0, w, h);
+            P[3][i] = pass3x3<DR, false>(P[6], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<DR, true>(P[0], lx, ly, gx0, gy0, w, h);
+            P[7][i] = pass3x3<DR, true>(P[5], lx, ly, gx0, gy0, w, h);
+            P[8][i] = pass3x3<DR, true>(P[6], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S4: second pass on the tile itself; write img, mu, sq
+    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+        const int tx = i % DT, ty = i / DT, lx = tx + 4, ly = ty + 4, X = x0 + tx, Y = y0 + ty;
+        if (X < w && Y < h) {
+            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
+            const int li = ly * DR + lx;
+            img[o] = P[0][li];
+            img[o + g.plane] = P[5][li];
+            img[o + 2 * g.plane] = P[6][li];
+            mu[o] = pass3x3<DR, false>(P[1], lx, ly, gx0, gy0, w, h);
+            mu[o + g.plane] = pass3x3<DR, false>(P[2], lx, ly, gx0, gy0, w, h);
+            mu[o + 2 * g.plane] = pass3x3<DR, false>(P[3], lx, ly, gx0, gy0, w, h);
+            sq[o] = pass3x3<DR, false>(P[4], lx, ly, gx0, gy0, w, h);
+            sq[o + g.plane] = pass3x3<DR, false>(P[7], lx, ly, gx0, gy0, w, h);
+            sq[o + 2 * g.plane] = pass3x3<DR, false>(P[8], lx, ly, gx0, gy0, w, h);
+        }
+    }
 }
 
 __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -153,43 +203,63 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
     return t;
 }
 
-// ---- compare_scale: SSIM over the channel-averaged statistics; writes the map and the block's sum ----
-__global__ __launch_bounds__(TPB) void k_dssim_ssim_map(const float *__restrict__ mu, const float *__restrict__ sq,
-                                                        const float *__restrict__ i12, const uint32_t *__restrict__ pair_ref,
-                                                        float *__restrict__ map, double *__restrict__ part, uint32_t w, uint32_t h,
-                                                        uint32_t pitch, size_t plane, uint32_t max_refs, uint32_t level,
-                                                        uint32_t n_levels, uint32_t n_blocks)
+// ---- Dssim::compare for one level, fused: i12 = blur(img1*img2) in LDS (tile + halo 2), then compare_scale ----
+constexpr int CR = DT + 4;
+__global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ mu,
+                                                       const float *__restrict__ sq, const uint32_t *__restrict__ pair_ref,
+                                                       float *__restrict__ map, double *__restrict__ part, lvl_geom g,
+                                                       uint32_t max_refs, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
 {
+    __shared__ float M[3][CR * CR], T[3][CR * CR];
     __shared__ double s_red[TPB / 64];
     const uint32_t p = blockIdx.z;
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    double val = 0.0;
-    if (x < w && y < h) {
-        const size_t o = (size_t)y * pitch + x;
-        const size_t oa = (size_t)pair_ref[p] * 3 * plane + o, ob = (size_t)(max_refs + p) * 3 * plane + o;
-        const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
-        float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
+    const int w = (int)g.w, h = (int)g.h;
+    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 2, gy0 = y0 - 2;
+    const size_t sa = (size_t)pair_ref[p] * 3 * g.plane, sb = (size_t)(max_refs + p) * 3 * g.plane;
+    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
+        const int lx = i % CR, ly = i / CR;
+        const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
+        const size_t o = (size_t)Y * g.pitch + X;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float u1 = mu[oa + c * plane], u2 = mu[ob + c * plane];
-            m11[c] = u1 * u1;
-            m12[c] = u1 * u2;
-            m22[c] = u2 * u2;
-            s1[c] = sq[oa + c * plane] - m11[c];
-            s2[c] = sq[ob + c * plane] - m22[c];
-            s12[c] = i12[((size_t)p * 3 + c) * plane + o] - m12[c];
+        for (int c = 0; c < 3; c++) M[c][i] = img[sa + c * g.plane + o] * img[sb + c * g.plane + o];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
+        const int lx = i % CR, ly = i / CR;
+        if (lx >= 1 && lx < CR - 1 && ly >= 1 && ly < CR - 1 && gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, false>(M[c], lx, ly, gx0, gy0, w, h);
         }
+    }
+    __syncthreads();
+    double val = 0.0;
+    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+        const int tx = i % DT, ty = i / DT, lx = tx + 2, ly = ty + 2, X = x0 + tx, Y = y0 + ty;
+        if (X < w && Y < h) {
+            const size_t o = (size_t)Y * g.pitch + X;
+            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
+            float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float u1 = mu[sa + c * g.plane + o], u2 = mu[sb + c * g.plane + o];
+                m11[c] = u1 * u1;
+                m12[c] = u1 * u2;
+                m22[c] = u2 * u2;
+                s1[c] = sq[sa + c * g.plane + o] - m11[c];
+                s2[c] = sq[sb + c * g.plane + o] - m22[c];
+                s12[c] = pass3x3<CR, false>(T[c], lx, ly, gx0, gy0, w, h) - m12[c];
+            }
 #define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
-        const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
-        const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12);
+            const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
+            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12);
 #undef AVG3
-        const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
-        map[(size_t)p * plane + o] = ssim;
-        val = (double)ssim;
+            const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
+            map[(size_t)p * g.plane + o] = ssim;
+            val += (double)ssim;
+        }
     }
     const double t = block_sum(val, s_red);
-    if (threadIdx.x == 0)
-        part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
 // ---- avg = max(mean, 0)^(0.5^level): one block per pair reduces the SSIM partial sums in a fixed order ----
@@ -292,14 +362,13 @@ static int dssim_prepare(ce_batch *b)
     }
     b->ds_levels = n;
     const size_t slots = (size_t)b->max_refs + b->max_pairs, p0 = b->ds[0].plane;
-    CE_HIP(ctx, hipMalloc(&b->ds_lin[0], slots * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_lin[1], slots * 3 * p0 * sizeof(float)));
+    // linear RGB ping-pong for levels >= 1 (level 0 is read from the u8 slabs): level l lives in ds_lin[l & 1]
+    const size_t p1 = n > 1 ? b->ds[1].plane : 1;
+    CE_HIP(ctx, hipMalloc(&b->ds_lin[0], slots * 3 * p1 * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->ds_lin[1], slots * 3 * p1 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_img, slots * 3 * p0 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_mu, slots * 3 * p0 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_sq, slots * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_tmp[0], slots * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_tmp[1], slots * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_i12, (size_t)b->max_pairs * 3 * p0 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_map, (size_t)b->max_pairs * p0 * sizeof(float)));
     b->ds_blocks = ((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
@@ -317,50 +386,29 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     ds_geom g{};
     for (int l = 0; l < b->ds_levels; l++) {
         const auto &d = b->ds[l];
-        float *lin = b->ds_lin[l & 1];
-        const dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, n_slots);
-        if (l == 0) {
-            CE_LAUNCH(ctx, "dssim_linear_u8", k_dssim_linear_u8, grid, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_powf, lin,
-                      d.w, d.h, d.pitch, d.plane, b->img_bytes, n_refs_used, mr);
-        } else {
-            const auto &pd = b->ds[l - 1];
-            CE_LAUNCH(ctx, "dssim_downsample", k_dssim_downsample, dim3(grid.x, grid.y, n_slots * 3), dim3(TPB), 0,
-                      b->ds_lin[(l - 1) & 1], lin, pd.pitch, pd.plane, d.w, d.h, d.pitch, d.plane, n_refs_used, mr);
-        }
-        // create_image: LAB, chroma pre-blur, mu, sq  (planes-per-slot = 3 everywhere)
-        CE_LAUNCH(ctx, "dssim_lab", k_dssim_lab, grid, dim3(TPB), 0, lin, b->ds_img, d.w, d.h, d.pitch, d.plane, n_refs_used, mr);
-        const dim3 g2(grid.x, grid.y, n_slots * 2), g3(grid.x, grid.y, n_slots * 3);
-        const uint32_t *nomap = nullptr;
-        // chroma planes 1,2: img -> tmp0 -> img
-        CE_LAUNCH(ctx, "dssim_blur3x3", k_blur3x3<0>, g2, dim3(TPB), 0, b->ds_img, (const float *)nullptr, b->ds_tmp[0], d.w, d.h,
-                  d.pitch, d.plane, 2u, 3u, 1u, 3u, 1u, nomap, nomap, 0u, n_refs_used, mr, 0);
-        CE_LAUNCH(ctx, "dssim_blur3x3", k_blur3x3<0>, g2, dim3(TPB), 0, b->ds_tmp[0], (const float *)nullptr, b->ds_img, d.w, d.h,
-                  d.pitch, d.plane, 2u, 3u, 1u, 3u, 1u, nomap, nomap, 0u, n_refs_used, mr, 0);
-        // mu = blur(blur(img))
-        CE_LAUNCH(ctx, "dssim_blur3x3", k_blur3x3<0>, g3, dim3(TPB), 0, b->ds_img, (const float *)nullptr, b->ds_tmp[0], d.w, d.h,
-                  d.pitch, d.plane, 3u, 3u, 0u, 3u, 0u, nomap, nomap, 0u, n_refs_used, mr, 0);
-        CE_LAUNCH(ctx, "dssim_blur3x3", k_blur3x3<0>, g3, dim3(TPB), 0, b->ds_tmp[0], (const float *)nullptr, b->ds_mu, d.w, d.h,
-                  d.pitch, d.plane, 3u, 3u, 0u, 3u, 0u, nomap, nomap, 0u, n_refs_used, mr, 0);
-        // sq = blur(blur(img*img))
-        CE_LAUNCH(ctx, "dssim_blur3x3_sq", k_blur3x3<1>, g3, dim3(TPB), 0, b->ds_img, (const float *)nullptr, b->ds_tmp[1], d.w,
-                  d.h, d.pitch, d.plane, 3u, 3u, 0u, 3u, 0u, nomap, nomap, 0u, n_refs_used, mr, 0);
-        CE_LAUNCH(ctx, "dssim_blur3x3", k_blur3x3<0>, g3, dim3(TPB), 0, b->ds_tmp[1], (const float *)nullptr, b->ds_sq, d.w, d.h,
-                  d.pitch, d.plane, 3u, 3u, 0u, 3u, 0u, nomap, nomap, 0u, n_refs_used, mr, 0);
-        // compare: i12 = blur(blur(img1*img2)) per pair; pass 1 -> tmp0 (indexed by pair), pass 2 -> i12
-        const dim3 gp3(grid.x, grid.y, n_pairs * 3), gp(grid.x, grid.y, n_pairs);
-        CE_LAUNCH(ctx, "dssim_blur3x3_mul", k_blur3x3<2>, gp3, dim3(TPB), 0, b->ds_img, b->ds_img, b->ds_tmp[0], d.w, d.h, d.pitch,
-                  d.plane, 3u, 3u, 0u, 3u, 0u, (const uint32_t *)b->d_pair_ref, nomap, mr, n_refs_used, mr, 1);
-        CE_LAUNCH(ctx, "dssim_blur3x3", k_blur3x3<0>, gp3, dim3(TPB), 0, b->ds_tmp[0], (const float *)nullptr, b->ds_i12, d.w, d.h,
-                  d.pitch, d.plane, 3u, 3u, 0u, 3u, 0u, nomap, nomap, 0u, n_refs_used, mr, 1);
-        const uint32_t used_blocks = grid.x * grid.y;
-        CE_LAUNCH(ctx, "dssim_ssim_map", k_dssim_ssim_map, gp, dim3(TPB), 0, b->ds_mu, b->ds_sq, b->ds_i12, b->d_pair_ref, b->ds_map,
-                  b->ds_part, d.w, d.h, d.pitch, d.plane, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
+        const bool has_next = l + 1 < b->ds_levels;
+        const auto &nd = b->ds[has_next ? l + 1 : l];
+        const lvl_geom lg{d.w, d.h, d.pitch, d.plane}, ng{nd.w, nd.h, nd.pitch, nd.plane};
+        const dim3 tiles((d.w + DT - 1) / DT, (d.h + DT - 1) / DT, 1);
+        // create_image for every used slot (references once per reference)
+        if (l == 0)
+            CE_LAUNCH(ctx, "dssim_create_u8", k_dssim_create<true>, dim3(tiles.x, tiles.y, n_slots), dim3(TPB), 0, d_refs, b->d_tests,
+                      ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_mu, b->ds_sq, lg, ng, has_next ? 1 : 0,
+                      b->img_bytes, n_refs_used, mr);
+        else
+            CE_LAUNCH(ctx, "dssim_create", k_dssim_create<false>, dim3(tiles.x, tiles.y, n_slots), dim3(TPB), 0, d_refs, b->d_tests,
+                      ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img, b->ds_mu, b->ds_sq, lg, ng,
+                      has_next ? 1 : 0, b->img_bytes, n_refs_used, mr);
+        // compare per pair
+        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(tiles.x, tiles.y, n_pairs), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
+                  b->d_pair_ref, b->ds_map, b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
-                  (uint32_t)b->ds_levels, b->ds_blocks, used_blocks);
+                  (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
+        const dim3 gp((d.w + 63) / 64, (d.h + 3) / 4, n_pairs);
         CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, b->ds_map, b->ds_level_scores, b->ds_part, d.w, d.h,
                   d.pitch, d.plane, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         g.npix[l] = d.w * d.h;
-        g.nblk[l] = used_blocks;
+        g.nblk[l] = gp.x * gp.y;
     }
     CE_LAUNCH(ctx, "dssim_finalize", k_dssim_finalize_pairs, dim3((n_pairs + 63) / 64), dim3(64), 0, b->ds_part,
               b->ds_level_scores, b->d_scores, n_pairs, (uint32_t)b->ds_levels, b->ds_blocks, g);
