@@ -47,10 +47,10 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, ui
     return z < n_refs_used ? z : max_refs + (z - n_refs_used);
 }
 
-// ---- sRGB u8 -> linear planes -----------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_ba_linear_u8(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
-                                                      const float *__restrict__ lut, float *__restrict__ lin, geom g,
-                                                      size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+// ---- SubSample2x straight from the u8 slabs: out(x/2, y/2) += 0.25 * lin(x, y) in raster order; odd edges doubled ----
+__global__ __launch_bounds__(TPB) void k_ba_subsample2x_u8(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
+                                                           const float *__restrict__ lut, float *__restrict__ out, geom gi, geom g,
+                                                           size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
 {
     __shared__ float s_lut[256];
     s_lut[threadIdx.x] = lut[threadIdx.x];
@@ -58,31 +58,25 @@ __global__ __launch_bounds__(TPB) void k_ba_linear_u8(const uint8_t *__restrict_
     const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
     const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
     BA_XY;
-    const uint8_t *px = src + ((size_t)y * g.w + x) * 3;
-    float *dst = lin + (size_t)slot * 3 * g.plane + o;
-    dst[0] = s_lut[px[0]];
-    dst[g.plane] = s_lut[px[1]];
-    dst[2 * g.plane] = s_lut[px[2]];
-}
-
-// ---- SubSample2x: out(x/2, y/2) += 0.25 * in(x, y) in raster order; odd edges doubled ------------------
-__global__ __launch_bounds__(TPB) void k_ba_subsample2x(const float *__restrict__ in, float *__restrict__ out, geom gi, geom g,
-                                                        uint32_t n_refs_used, uint32_t max_refs)
-{
-    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs), c = blockIdx.z % 3;
-    BA_XY;
-    const float *p = in + ((size_t)slot * 3 + c) * gi.plane;
-    float acc = 0.0f;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (uint32_t dy = 0; dy < 2; dy++)
 #pragma unroll
         for (uint32_t dx = 0; dx < 2; dx++) {
             const uint32_t ix = 2 * x + dx, iy = 2 * y + dy;
-            if (ix < gi.w && iy < gi.h) acc += 0.25f * p[(size_t)iy * gi.pitch + ix];
+            if (ix < gi.w && iy < gi.h) {
+                const uint8_t *px = src + ((size_t)iy * gi.w + ix) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[c] += 0.25f * s_lut[px[c]];
+            }
         }
-    if ((gi.w & 1) && x == g.w - 1) acc *= 2.0f;
-    if ((gi.h & 1) && y == g.h - 1) acc *= 2.0f;
-    out[((size_t)slot * 3 + c) * g.plane + o] = acc;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v = acc[c];
+        if ((gi.w & 1) && x == g.w - 1) v *= 2.0f;
+        if ((gi.h & 1) && y == g.h - 1) v *= 2.0f;
+        out[((size_t)slot * 3 + c) * g.plane + o] = v;
+    }
 }
 
 // ---- separable blurs ------------------------------------------------------------------------------------
@@ -95,30 +89,6 @@ __device__ __forceinline__ uint32_t mirror(int x, int n)
 {
     while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
     return (uint32_t)x;
-}
-
-template <bool VERT>
-__global__ __launch_bounds__(TPB) void k_ba_blur5_mirror(const float *__restrict__ in, float *__restrict__ out, geom g,
-                                                         plane_sel si, plane_sel so, float w0, float w1, float w2,
-                                                         uint32_t n_refs_used, uint32_t max_refs, int by_slot)
-{
-    const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
-    const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
-    BA_XY;
-    const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
-    float r;
-    if (!VERT) {
-        const float *row = p + (size_t)y * g.pitch;
-        const int X = (int)x, W = (int)g.w;
-        r = row[x] * w0 + (row[mirror(X - 1, W)] + row[mirror(X + 1, W)]) * w1 + (row[mirror(X - 2, W)] + row[mirror(X + 2, W)]) * w2;
-    } else {
-        const int Y = (int)y, H = (int)g.h;
-        const float *col = p + x;
-        r = col[(size_t)y * g.pitch] * w0 +
-            (col[(size_t)mirror(Y - 1, H) * g.pitch] + col[(size_t)mirror(Y + 1, H) * g.pitch]) * w1 +
-            (col[(size_t)mirror(Y - 2, H) * g.pitch] + col[(size_t)mirror(Y + 2, H) * g.pitch]) * w2;
-    }
-    out[((size_t)unit * so.per_unit + so.first + k) * g.plane + o] = r;
 }
 
 // Long separable blurs, LDS-tiled with a register window: a thread produces 8 consecutive outputs
@@ -234,37 +204,93 @@ __device__ __forceinline__ float gamma_f(float v)
     return __builtin_fmaf(kRetMul, log2f(biased), kRetAdd);
 }
 
-__global__ __launch_bounds__(TPB) void k_ba_opsin(const float *__restrict__ lin, const float *__restrict__ blurred,
-                                                  float *__restrict__ xyb, geom g, float intensity_target, uint32_t n_refs_used,
-                                                  uint32_t max_refs)
+// Front end, fused: linear RGB tile (level 0: sRGB u8 through the table; level 1: the subsampled planes) with a
+// 2-pixel halo in LDS -> the 5-tap sigma-1.2 blur (mirrored at the image border, both passes in LDS) ->
+// OpsinDynamicsImage -> XYB planes.  Only XYB is written (12 B/px); nothing else of this stage touches HBM.
+constexpr int FT = 32, FR = FT + 4;
+template <bool FROM_U8>
+__global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
+                                                  const float *__restrict__ lut, const float *__restrict__ lin_in,
+                                                  float *__restrict__ xyb, geom g, float w0, float w1, float w2,
+                                                  float intensity_target, size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
 {
-    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
-    BA_XY;
-    const size_t b = (size_t)slot * 3 * g.plane + o;
-    const float mn = 1e-4f;
-    float p0, p1, p2;
-    opsin_absorbance(blurred[b] * intensity_target, blurred[b + g.plane] * intensity_target,
-                     blurred[b + 2 * g.plane] * intensity_target, p0, p1, p2);
-    p0 = p0 > mn ? p0 : mn;
-    p1 = p1 > mn ? p1 : mn;
-    p2 = p2 > mn ? p2 : mn;
-    float s0 = gamma_f(p0) / p0, s1 = gamma_f(p1) / p1, s2 = gamma_f(p2) / p2;
-    s0 = s0 > mn ? s0 : mn;
-    s1 = s1 > mn ? s1 : mn;
-    s2 = s2 > mn ? s2 : mn;
-    float c0, c1, c2;
-    opsin_absorbance(lin[b] * intensity_target, lin[b + g.plane] * intensity_target, lin[b + 2 * g.plane] * intensity_target, c0,
-                     c1, c2);
-    c0 *= s0;
-    c1 *= s1;
-    c2 *= s2;
-    const float min01 = 1.7557483643287353f, min2 = 12.226454707163354f;
-    c0 = c0 > min01 ? c0 : min01;
-    c1 = c1 > min01 ? c1 : min01;
-    c2 = c2 > min2 ? c2 : min2;
-    xyb[b] = c0 - c1;
-    xyb[b + g.plane] = c0 + c1;
-    xyb[b + 2 * g.plane] = c2;
+    __shared__ float L[3][FR * FR];   // linear, region = tile + 2
+    __shared__ float H[3][FR * FT];   // row-blurred: FR rows x FT columns
+    __shared__ float s_lut[256];
+    if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
+    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const int w = (int)g.w, h = (int)g.h, x0 = blockIdx.x * FT, y0 = blockIdx.y * FT, gx0 = x0 - 2, gy0 = y0 - 2;
+    const uint8_t *src8 = nullptr;
+    if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
+    const float *srcf = lin_in + (size_t)slot * 3 * g.plane;
+    __syncthreads();
+    for (int i = threadIdx.x; i < FR * FR; i += TPB) {
+        const int lx = i % FR, ly = i / FR, X = gx0 + lx, Y = gy0 + ly;
+        if (X >= 0 && X < w && Y >= 0 && Y < h) {
+            if (FROM_U8) {
+                const uint8_t *px = src8 + ((size_t)Y * w + X) * 3;
+                L[0][i] = s_lut[px[0]];
+                L[1][i] = s_lut[px[1]];
+                L[2][i] = s_lut[px[2]];
+            } else {
+                const size_t o = (size_t)Y * g.pitch + X;
+                L[0][i] = srcf[o];
+                L[1][i] = srcf[o + g.plane];
+                L[2][i] = srcf[o + 2 * g.plane];
+            }
+        }
+    }
+    __syncthreads();
+    // row pass on every in-image row of the region, tile columns only; mirror in GLOBAL coordinates
+    for (int i = threadIdx.x; i < FR * FT; i += TPB) {
+        const int tx = i % FT, ly = i / FT, X = x0 + tx, Y = gy0 + ly;
+        if (X < w && Y >= 0 && Y < h) {
+            const int c0 = X - gx0, m1 = (int)mirror(X - 1, w) - gx0, p1 = (int)mirror(X + 1, w) - gx0,
+                      m2 = (int)mirror(X - 2, w) - gx0, p2 = (int)mirror(X + 2, w) - gx0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float *r = &L[c][ly * FR];
+                H[c][i] = r[c0] * w0 + (r[m1] + r[p1]) * w1 + (r[m2] + r[p2]) * w2;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FT * FT; i += TPB) {
+        const int tx = i % FT, ty = i / FT, X = x0 + tx, Y = y0 + ty;
+        if (X >= w || Y >= h) continue;
+        const int r0 = Y - gy0, rm1 = (int)mirror(Y - 1, h) - gy0, rp1 = (int)mirror(Y + 1, h) - gy0,
+                  rm2 = (int)mirror(Y - 2, h) - gy0, rp2 = (int)mirror(Y + 2, h) - gy0;
+        float bl[3], ln[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float *col = &H[c][tx];
+            bl[c] = col[r0 * FT] * w0 + (col[rm1 * FT] + col[rp1 * FT]) * w1 + (col[rm2 * FT] + col[rp2 * FT]) * w2;
+            ln[c] = L[c][(ty + 2) * FR + tx + 2];
+        }
+        const float mn = 1e-4f;
+        float p0, p1v, p2v;
+        opsin_absorbance(bl[0] * intensity_target, bl[1] * intensity_target, bl[2] * intensity_target, p0, p1v, p2v);
+        p0 = p0 > mn ? p0 : mn;
+        p1v = p1v > mn ? p1v : mn;
+        p2v = p2v > mn ? p2v : mn;
+        float s0 = gamma_f(p0) / p0, s1 = gamma_f(p1v) / p1v, s2 = gamma_f(p2v) / p2v;
+        s0 = s0 > mn ? s0 : mn;
+        s1 = s1 > mn ? s1 : mn;
+        s2 = s2 > mn ? s2 : mn;
+        float c0, c1, c2;
+        opsin_absorbance(ln[0] * intensity_target, ln[1] * intensity_target, ln[2] * intensity_target, c0, c1, c2);
+        c0 *= s0;
+        c1 *= s1;
+        c2 *= s2;
+        const float min01 = 1.7557483643287353f, min2 = 12.226454707163354f;
+        c0 = c0 > min01 ? c0 : min01;
+        c1 = c1 > min01 ? c1 : min01;
+        c2 = c2 > min2 ? c2 : min2;
+        const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
+        xyb[o] = c0 - c1;
+        xyb[o + g.plane] = c0 + c1;
+        xyb[o + 2 * g.plane] = c2;
+    }
 }
 
 // ---- SeparateFrequencies pointwise stages ------------------------------------------------------------------
@@ -352,41 +378,6 @@ struct malta_params {
     float norm2_0gt1, norm2_0lt1, norm1;
 };
 
-__global__ __launch_bounds__(TPB) void k_ba_malta_diffs(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
-                                                        float *__restrict__ diffs, geom g, uint32_t max_refs, uint32_t plane_idx,
-                                                        malta_params mp)
-{
-    const uint32_t p = blockIdx.z;
-    BA_XY;
-    const float v0 = psy[((size_t)pair_ref[p] * PSY + plane_idx) * g.plane + o];
-    const float v1 = psy[((size_t)(max_refs + p) * PSY + plane_idx) * g.plane + o];
-    const float absval = 0.5f * (fabsf(v0) + fabsf(v1));
-    const float diff = v0 - v1;
-    const float scaler = mp.norm2_0gt1 / (mp.norm1 + absval);
-    float r = scaler * diff;
-    const float scaler2 = mp.norm2_0lt1 / (mp.norm1 + absval);
-    const double fabs0 = fabs((double)v0);
-    const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
-    if (v0 < 0) {
-        if (v1 > -too_small) {
-            const double impact = scaler2 * (v1 + too_small);
-            r = (float)(r - impact);
-        } else if (v1 < -too_big) {
-            const double impact = scaler2 * (-v1 - too_big);
-            r = (float)(r + impact);
-        }
-    } else {
-        if (v1 < too_small) {
-            const double impact = scaler2 * (too_small - v1);
-            r = (float)(r + impact);
-        } else if (v1 > too_big) {
-            const double impact = scaler2 * (v1 - too_big);
-            r = (float)(r - impact);
-        }
-    }
-    diffs[(size_t)p * g.plane + o] = r;
-}
-
 struct mline {
     int n;
     signed char d[9][2];
@@ -429,27 +420,54 @@ __device__ constexpr mline MALTA_LF[16] = {
     {5, {{2, -4}, {1, -2}, {0, 0}, {-1, 2}, {-2, 4}}},
 };
 
-// 32x32 outputs per block from a zero-padded 40x40 LDS tile; ac += sum over 16 lines of (line sum)^2
-constexpr int MT = 32, MH = 4, ML = MT + 2 * MH;
-template <bool LF>
-__global__ __launch_bounds__(TPB) void k_ba_malta(const float *__restrict__ diffs, float *__restrict__ ac, geom g)
+constexpr int MT = 32, MH = 4, ML = MT + 2 * MH;  // 32x32 outputs per block from a zero-padded 40x40 LDS tile
+
+// ---- per pair, fused: the three Malta bands of one channel + that channel's L2 terms -----------------------------
+// For channel c in {X, Y}: UHF (9-sample lines), HF and MF (5-sample lines).  Per band the two images' 40x40
+// regions are read once, the asymmetric pre-scaled difference (MaltaDiffMap's first loop) goes to LDS (zero outside
+// the image, as PaddedMaltaUnit does) and the 16 line sums are squared and accumulated in registers.  Then the
+// L2DiffAsymmetric (HF), L2Diff (MF) and SetL2Diff (LF) terms of the channel are added and ac[c] / dc[c] are written
+// once.  Channel B has no Malta term: only L2Diff (MF) and SetL2Diff (LF).
+struct malta_bands {
+    malta_params p[2][3];  // [channel][band: uhf, hf, mf]
+};
+
+__device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_params &mp)
 {
-    __shared__ float s[ML * ML];
-    const uint32_t p = blockIdx.z;
-    const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MT - MH;
-    const float *d = diffs + (size_t)p * g.plane;
-    for (int i = threadIdx.x; i < ML * ML; i += TPB) {
-        const int lx = i % ML, ly = i / ML, gx = x0 + lx, gy = y0 + ly;
-        s[i] = (gx >= 0 && gy >= 0 && gx < (int)g.w && gy < (int)g.h) ? d[(size_t)gy * g.pitch + gx] : 0.0f;
+    const float absval = 0.5f * (fabsf(v0) + fabsf(v1));
+    const float diff = v0 - v1;
+    const float scaler = mp.norm2_0gt1 / (mp.norm1 + absval);
+    float r = scaler * diff;
+    const float scaler2 = mp.norm2_0lt1 / (mp.norm1 + absval);
+    const double fabs0 = fabs((double)v0);
+    const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
+    if (v0 < 0) {
+        if (v1 > -too_small) {
+            const double impact = scaler2 * (v1 + too_small);
+            r = (float)(r - impact);
+        } else if (v1 < -too_big) {
+            const double impact = scaler2 * (-v1 - too_big);
+            r = (float)(r + impact);
+        }
+    } else {
+        if (v1 < too_small) {
+            const double impact = scaler2 * (too_small - v1);
+            r = (float)(r + impact);
+        } else if (v1 > too_big) {
+            const double impact = scaler2 * (v1 - too_big);
+            r = (float)(r - impact);
+        }
     }
-    __syncthreads();
-    const int tx = threadIdx.x & 31, ty0 = threadIdx.x >> 5;
+    return r;
+}
+
+// The 16 line sums of MaltaUnit for FOUR horizontally adjacent centres, from a 9 x 12 register window
+// (27 16-byte LDS reads instead of 4 x 128 scalar ones).  Tap order per line as in the lineage.
+template <bool LF>
+__device__ __forceinline__ void malta_unit4(const float (&win)[9][12], float (&acc)[4])
+{
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int ty = ty0 + 8 * r;
-        const uint32_t x = blockIdx.x * MT + tx, y = blockIdx.y * MT + ty;
-        if (x >= g.w || y >= g.h) continue;
-        const float *c = s + (ty + MH) * ML + tx + MH;
+    for (int o = 0; o < 4; o++) {
         float ret = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -457,32 +475,73 @@ __global__ __launch_bounds__(TPB) void k_ba_malta(const float *__restrict__ diff
             float sum = 0.0f;
 #pragma unroll
             for (int j = 0; j < 9; j++)
-                if (j < ln.n) sum += c[ln.d[j][1] * ML + ln.d[j][0]];
+                if (j < ln.n) sum += win[4 + ln.d[j][1]][4 + o + ln.d[j][0]];
             ret = __builtin_fmaf(sum, sum, ret);
         }
-        ac[(size_t)p * g.plane + (size_t)y * g.pitch + x] += ret;
+        acc[o] += ret;
     }
 }
 
-// ---- per pair: L2 terms (fills dc[0..2], adds to ac[0..2]) -----------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_ba_l2(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
-                                               float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
-                                               uint32_t n_pairs_stride)
+__global__ __launch_bounds__(TPB) void k_ba_malta_l2(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+                                                     float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
+                                                     uint32_t n_pairs_stride, malta_bands mb)
 {
-    const uint32_t p = blockIdx.z;
-    BA_XY;
-    const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane + o;
-    const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane + o;
+    __shared__ __attribute__((aligned(16))) float s[ML * ML];
+    const uint32_t p = blockIdx.z / 3, c = blockIdx.z % 3;
+    const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MT - MH;
+    const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane;
+    const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane;
+    // thread -> four adjacent outputs: columns 4*tq .. 4*tq+3 of tile row ty
+    const int tq = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < 2) {
+        const uint32_t band_plane[3] = {UHF0 + c, HF0 + c, MF0 + c};
+#pragma unroll
+        for (int band = 0; band < 3; band++) {
+            const malta_params mp = mb.p[c][band];
+            const float *pa = a + (size_t)band_plane[band] * g.plane, *pb = b + (size_t)band_plane[band] * g.plane;
+            for (int i = threadIdx.x; i < ML * ML; i += TPB) {
+                const int lx = i % ML, ly = i / ML, gx = x0 + lx, gy = y0 + ly;
+                float v = 0.0f;
+                if (gx >= 0 && gy >= 0 && gx < (int)g.w && gy < (int)g.h) {
+                    const size_t o = (size_t)gy * g.pitch + gx;
+                    v = malta_pre_diff(pa[o], pb[o], mp);
+                }
+                s[i] = v;
+            }
+            __syncthreads();
+            float win[9][12];
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                const float4 *row = reinterpret_cast<const float4 *>(s + (ty + r) * ML + 4 * tq);
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const float4 v = row[q];
+                    win[r][4 * q] = v.x;
+                    win[r][4 * q + 1] = v.y;
+                    win[r][4 * q + 2] = v.z;
+                    win[r][4 * q + 3] = v.w;
+                }
+            }
+            // block_diff_ac accumulates band by band in the lineage: same order here
+            if (band == 0)
+                malta_unit4<false>(win, acc);
+            else
+                malta_unit4<true>(win, acc);
+            __syncthreads();
+        }
+    }
     const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
     const float hf_asymmetry = 1.0f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float *pac = ac + ((size_t)c * n_pairs_stride + p) * g.plane + o;
-        float total = *pac;
+    for (int r = 0; r < 4; r++) {
+        const uint32_t x = blockIdx.x * MT + 4 * tq + r, y = blockIdx.y * MT + ty;
+        if (x >= g.w || y >= g.h) continue;
+        const size_t o = (size_t)y * g.pitch + x;
+        float total = acc[r];
         if (c < 2) {  // L2DiffAsymmetric on hf[c]
-            const float w_0gt1 = wmul[c] * hf_asymmetry, w_0lt1 = wmul[c] / hf_asymmetry;
-            const float vw_0gt1 = w_0gt1 * 0.8f, vw_0lt1 = w_0lt1 * 0.8f;
-            const float val0 = a[(HF0 + c) * g.plane], val1 = b[(HF0 + c) * g.plane];
+            const float vw_0gt1 = wmul[c] * hf_asymmetry * 0.8f, vw_0lt1 = wmul[c] / hf_asymmetry * 0.8f;
+            const float val0 = a[(HF0 + c) * g.plane + o], val1 = b[(HF0 + c) * g.plane + o];
             const float diff = val0 - val1;
             total = __builtin_fmaf(diff * diff, vw_0gt1, total);
             const float fabs0 = fabsf(val0);
@@ -493,33 +552,38 @@ __global__ __launch_bounds__(TPB) void k_ba_l2(const float *__restrict__ psy, co
             total = __builtin_fmaf(vw_0lt1, v * v, total);
         }
         {  // L2Diff on mf[c]
-            const float diff = a[(MF0 + c) * g.plane] - b[(MF0 + c) * g.plane];
+            const float diff = a[(MF0 + c) * g.plane + o] - b[(MF0 + c) * g.plane + o];
             total = __builtin_fmaf(diff * diff, wmul[3 + c], total);
         }
-        *pac = total;
+        ac[((size_t)c * n_pairs_stride + p) * g.plane + o] = total;
         {  // SetL2Diff on lf[c]
-            const float diff = a[(LF0 + c) * g.plane] - b[(LF0 + c) * g.plane];
+            const float diff = a[(LF0 + c) * g.plane + o] - b[(LF0 + c) * g.plane + o];
             dc[((size_t)c * n_pairs_stride + p) * g.plane + o] = (diff * diff) * wmul[6 + c];
         }
     }
 }
 
 // ---- per pair: mask -----------------------------------------------------------------------------------------------
-// which = 0: reference image, 1: test image.  out = DiffPrecompute(sqrt(xdiff^2 + ydiff^2))
-__global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
-                                                     float *__restrict__ out, geom g, uint32_t max_refs, int which)
+// DiffPrecompute(sqrt(xdiff^2 + ydiff^2)) of the reference (m0) and the test image (m1) of a pair
+__device__ __forceinline__ float mask_pre_one(const float *__restrict__ a, size_t plane)
 {
-    const uint32_t p = blockIdx.z;
-    BA_XY;
-    const float *a = psy + (size_t)(which ? max_refs + p : pair_ref[p]) * PSY * g.plane + o;
     const float muls[3] = {2.5f, 0.4f, 0.4f};
-    const float xdiff = (a[UHF0 * g.plane] + a[HF0 * g.plane]) * muls[0];
-    const float ydiff = a[UHF1 * g.plane] * muls[1] + a[HF1 * g.plane] * muls[2];
+    const float xdiff = (a[UHF0 * plane] + a[HF0 * plane]) * muls[0];
+    const float ydiff = a[UHF1 * plane] * muls[1] + a[HF1 * plane] * muls[2];
     const float m = sqrtf(xdiff * xdiff + ydiff * ydiff);
     const float kMul = 6.19424080439f, kBias = 12.61050594197f;
     const float bias = kMul * kBias;
     const float sqrt_bias = sqrtf(bias);
-    out[(size_t)p * g.plane + o] = sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
+    return sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
+}
+
+__global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+                                                     float *__restrict__ m0, float *__restrict__ m1, geom g, uint32_t max_refs)
+{
+    const uint32_t p = blockIdx.z;
+    BA_XY;
+    m0[(size_t)p * g.plane + o] = mask_pre_one(psy + (size_t)pair_ref[p] * PSY * g.plane + o, g.plane);
+    m1[(size_t)p * g.plane + o] = mask_pre_one(psy + (size_t)(max_refs + p) * PSY * g.plane + o, g.plane);
 }
 
 __device__ __forceinline__ void store_min3(float v, float &min0, float &min1, float &min2)
@@ -538,9 +602,10 @@ __device__ __forceinline__ void store_min3(float v, float &min0, float &min1, fl
     }
 }
 
-// mask = FuzzyErosion(blurred0);  ac[1] += 10 (blurred0 - blurred1)^2
-__global__ __launch_bounds__(TPB) void k_ba_mask_finish(const float *__restrict__ bl0, const float *__restrict__ bl1,
-                                                        float *__restrict__ mask, float *__restrict__ ac1, geom g)
+// mask = FuzzyErosion(blurred0); ac[1] += 10 (blurred0 - blurred1)^2; then CombineChannelsToDiffmap — one pass
+__global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict__ bl0, const float *__restrict__ bl1,
+                                                         const float *__restrict__ ac, const float *__restrict__ dc,
+                                                         float *__restrict__ diffmap, geom g, uint32_t n_pairs_stride)
 {
     const uint32_t p = blockIdx.z;
     BA_XY;
@@ -560,20 +625,11 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_finish(const float *__restrict_
     }
     if (Y >= S) store_min3(at(Y - S, X), min0, min1, min2);
     if (Y < H - S) store_min3(at(Y + S, X), min0, min1, min2);
-    mask[(size_t)p * g.plane + o] = 0.45f * min0 + 0.3f * min1 + 0.25f * min2;
-    const float diff = at(Y, X) - bl1[(size_t)p * g.plane + o];
-    ac1[(size_t)p * g.plane + o] += 10.0f * diff * diff;
-}
+    const float mask = 0.45f * min0 + 0.3f * min1 + 0.25f * min2;
+    const float mdiff = at(Y, X) - bl1[(size_t)p * g.plane + o];
 
-// ---- CombineChannelsToDiffmap --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_ba_combine(const float *__restrict__ mask, const float *__restrict__ ac,
-                                                    const float *__restrict__ dc, float *__restrict__ diffmap, geom g,
-                                                    uint32_t n_pairs_stride)
-{
-    const uint32_t p = blockIdx.z;
-    BA_XY;
     const double kGlobalScale = 1.0 / (17.83 * 0.790799174);
-    const double val = (double)mask[(size_t)p * g.plane + o];
+    const double val = (double)mask;
     double c = 2.5485944793 / ((0.451936922203 * val) + 0.829591754942);
     double rv = kGlobalScale * (1.0 + c);
     const float maskval = (float)(rv * rv);
@@ -586,17 +642,13 @@ __global__ __launch_bounds__(TPB) void k_ba_combine(const float *__restrict__ ma
         d_ac[k] = ac[((size_t)k * n_pairs_stride + p) * g.plane + o];
         d_dc[k] = dc[((size_t)k * n_pairs_stride + p) * g.plane + o];
     }
+    d_ac[1] += 10.0f * mdiff * mdiff;  // kMaskToErrorMul
     const float xmul = 1.0f;
     d_ac[0] *= xmul;
     d_dc[0] *= xmul;
     const float mc_dc = d_dc[0] * dc_maskval + d_dc[1] * dc_maskval + d_dc[2] * dc_maskval;
     const float mc_ac = d_ac[0] * maskval + d_ac[1] * maskval + d_ac[2] * maskval;
     diffmap[(size_t)p * g.plane + o] = sqrtf(mc_dc + mc_ac);
-}
-
-__global__ __launch_bounds__(TPB) void k_ba_zero(float *__restrict__ buf, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB) buf[i] = 0.0f;
 }
 
 // AddSupersampled2x (weight 0.5) fused with the final reductions: max, sum d^3, d^6, d^12
@@ -777,7 +829,7 @@ static int ba_prepare(ce_batch *b)
     b->ba_levels = (b->ba[1].w >= 8 && b->ba[1].h >= 8) ? 2 : 1;
     const size_t slots = (size_t)b->max_refs + b->max_pairs, P = b->max_pairs, p0 = b->ba[0].plane;
     for (int l = 0; l < b->ba_levels; l++) {
-        CE_HIP(ctx, hipMalloc(&b->ba_lin[l], slots * 3 * b->ba[l].plane * sizeof(float)));
+        if (l == 1) CE_HIP(ctx, hipMalloc(&b->ba_lin[l], slots * 3 * b->ba[l].plane * sizeof(float)));  // level 0 reads u8
         CE_HIP(ctx, hipMalloc(&b->ba_psy[l], slots * PSY * b->ba[l].plane * sizeof(float)));
         CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));
     }
@@ -819,18 +871,18 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         auto G = [&](uint32_t z) { return dim3(gx.x, gx.y, z); };
         float *lin = b->ba_lin[l], *psy = b->ba_psy[l], *sA = b->ba_s[0], *sB = b->ba_s[1], *sC = b->ba_s[2];
         // ---- per image slot: PsychoImage ----
+        const plane_sel s3{3, 0, 3};
+        const dim3 ft((d.w + FT - 1) / FT, (d.h + FT - 1) / FT, n_slots);
         if (l == 0) {
-            CE_LAUNCH(ctx, "ba_linear_u8", k_ba_linear_u8, G(n_slots), dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, lin, g,
-                      b->img_bytes, n_refs_used, mr);
+            CE_LAUNCH(ctx, "ba_front_u8", k_ba_front<true>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
+                      (const float *)nullptr, sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr);
         } else {
             const auto &pd = b->ba[0];
-            CE_LAUNCH(ctx, "ba_subsample2x", k_ba_subsample2x, G(n_slots * 3), dim3(TPB), 0, b->ba_lin[0], lin,
-                      geom{pd.w, pd.h, pd.pitch, pd.plane}, g, n_refs_used, mr);
+            CE_LAUNCH(ctx, "ba_subsample2x", k_ba_subsample2x_u8, G(n_slots), dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, lin,
+                      geom{pd.w, pd.h, pd.pitch, pd.plane}, g, b->img_bytes, n_refs_used, mr);
+            CE_LAUNCH(ctx, "ba_front", k_ba_front<false>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, (const float *)lin,
+                      sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr);
         }
-        const plane_sel s3{3, 0, 3};
-        CE_LAUNCH(ctx, "ba_blur5", k_ba_blur5_mirror<false>, G(n_slots * 3), dim3(TPB), 0, lin, sA, g, s3, s3, w0, w1, w2, n_refs_used, mr, 1);
-        CE_LAUNCH(ctx, "ba_blur5", k_ba_blur5_mirror<true>, G(n_slots * 3), dim3(TPB), 0, sA, sB, g, s3, s3, w0, w1, w2, n_refs_used, mr, 1);
-        CE_LAUNCH(ctx, "ba_opsin", k_ba_opsin, G(n_slots), dim3(TPB), 0, lin, sB, sC, g, intensity_target, n_refs_used, mr);  // sC = xyb
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
         const plane_sel sLf{PSY, LF0, 3}, sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
         if ((rc = launch_blur(ctx, sC, sA, psy, g, s3, s3, sLf, kLf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
@@ -843,31 +895,19 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         CE_LAUNCH(ctx, "ba_split_hf", k_ba_split_hf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
 
         // ---- per pair ----
-        float *diffs = b->ba_pp[0], *ac = b->ba_pp[1], *dc = b->ba_pp[2], *m0 = b->ba_pp[3], *m1 = b->ba_pp[4],
-              *bl0 = b->ba_pp[5], *bl1 = b->ba_pp[6], *tmp = b->ba_pp[7], *mask = b->ba_pp[8];
-        CE_LAUNCH(ctx, "ba_zero", k_ba_zero, dim3(2048), dim3(TPB), 0, ac, (size_t)P * 3 * b->ba[0].plane);
-        const dim3 mg((d.w + MT - 1) / MT, (d.h + MT - 1) / MT, n_pairs);
-        struct mcall { uint32_t plane_idx; malta_params mp; bool lf; int c; };
-        const mcall calls[6] = {{UHF1, mUhfY, false, 1}, {UHF0, mUhfX, false, 0}, {HF1, mHfY, true, 1},
-                                {HF0, mHfX, true, 0},    {MF1, mMfY, true, 1},    {MF0, mMfX, true, 0}};
-        for (const mcall &mc : calls) {
-            CE_LAUNCH(ctx, "ba_malta_diffs", k_ba_malta_diffs, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, diffs, g, mr,
-                      mc.plane_idx, mc.mp);
-            float *acc = ac + (size_t)mc.c * P * d.plane;
-            if (mc.lf)
-                CE_LAUNCH(ctx, "ba_malta_lf", k_ba_malta<true>, mg, dim3(TPB), 0, diffs, acc, g);
-            else
-                CE_LAUNCH(ctx, "ba_malta_hf", k_ba_malta<false>, mg, dim3(TPB), 0, diffs, acc, g);
-        }
-        CE_LAUNCH(ctx, "ba_l2", k_ba_l2, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P);
+        float *ac = b->ba_pp[1], *dc = b->ba_pp[2], *m0 = b->ba_pp[3], *m1 = b->ba_pp[4],
+              *bl0 = b->ba_pp[5], *bl1 = b->ba_pp[6], *tmp = b->ba_pp[7];
+        const dim3 mg((d.w + MT - 1) / MT, (d.h + MT - 1) / MT, n_pairs * 3);
+        malta_bands mb;
+        mb.p[0][0] = mUhfX; mb.p[0][1] = mHfX; mb.p[0][2] = mMfX;
+        mb.p[1][0] = mUhfY; mb.p[1][1] = mHfY; mb.p[1][2] = mMfY;
+        CE_LAUNCH(ctx, "ba_malta_l2", k_ba_malta_l2, mg, dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P, mb);
         // mask
         const plane_sel s1{1, 0, 1};
-        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m0, g, mr, 0);
-        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m1, g, mr, 1);
+        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m0, m1, g, mr);
         if ((rc = launch_blur(ctx, m0, tmp, bl0, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
         if ((rc = launch_blur(ctx, m1, tmp, bl1, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "ba_mask_finish", k_ba_mask_finish, G(n_pairs), dim3(TPB), 0, bl0, bl1, mask, ac + (size_t)1 * P * d.plane, g);
-        CE_LAUNCH(ctx, "ba_combine", k_ba_combine, G(n_pairs), dim3(TPB), 0, mask, ac, dc, b->ba_diff[l], g, P);
+        CE_LAUNCH(ctx, "ba_mask_combine", k_ba_mask_combine, G(n_pairs), dim3(TPB), 0, bl0, bl1, ac, dc, b->ba_diff[l], g, P);
     }
     const auto &d0 = b->ba[0];
     const geom g0{d0.w, d0.h, d0.pitch, d0.plane};
