@@ -186,34 +186,45 @@ __device__ __forceinline__ void lds_barrier()
 // one, which supplies the filter's left tap (10 columns back) for the first 10 steps, so all
 // LDS offsets are compile-time constants.  Outputs leave through a second LDS tile as
 // coalesced 16-byte row stores.
-#ifndef HB_ABLATE
-#define HB_ABLATE 0
-#endif
 constexpr int HB_ROWS = 64, HB_CW = 32, HB_LD = 65, HB_THREADS = 64 * CE_SSIM2_STREAMS;
 constexpr int HB_HALF = HB_CW * HB_LD;
 
 // Every stream is in[i] = P[i] * Q[i] with (P, Q) = (a, 1), (b, 1), (a, a), (b, b), (a, b).
-// One chunk = 32 filter steps: step e consumes the tile's column e (right tap) and the column
-// 10 back (left tap; for e < 10 that is in the previous chunk's half) and emits one output.
+// One chunk = 32 filter steps: step e consumes the tile's column e (right tap) and the input 10 steps
+// back (left tap, kept in a register delay line) and emits one output.
 template <bool PLAIN>
-__device__ __forceinline__ void hblur_chunk(const float *__restrict__ p_cur, const float *__restrict__ p_old,
-                                            const float *__restrict__ q_cur, const float *__restrict__ q_old,
-                                            float *__restrict__ so, float (&prev)[3], float (&prev2)[3],
-                                            const rg_consts &rg)
+__device__ __forceinline__ void hblur_chunk(const float *__restrict__ p_cur, const float *__restrict__ q_cur,
+                                            float *__restrict__ so, float (&dp)[10], float (&dq)[10], float (&prev)[3],
+                                            float (&prev2)[3], const rg_consts &rg)
 {
+    // dp/dq: the last 10 inputs (a 10-deep delay line in registers): slot e % 10 holds input e - 10
 #pragma unroll
     for (int e = 0; e < HB_CW; e++) {
         const float pr = p_cur[e * HB_LD];
-        const float pl = e >= 10 ? p_cur[(e - 10) * HB_LD] : p_old[(HB_CW - 10 + e) * HB_LD];
+        const float pl = dp[e % 10];
+        dp[e % 10] = pr;
         float sum;
         if (PLAIN) {
             sum = pl + pr;
         } else {
             const float qr = q_cur[e * HB_LD];
-            const float ql = e >= 10 ? q_cur[(e - 10) * HB_LD] : q_old[(HB_CW - 10 + e) * HB_LD];
+            const float ql = dq[e % 10];
+            dq[e % 10] = qr;
             sum = pl * ql + pr * qr;
         }
         so[e * HB_LD] = rg_step(sum, prev, prev2, rg);
+    }
+    // 32 steps advance the ring phase by 2: rotate so that the next chunk starts at slot 0 again
+    float tp[10], tq[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        tp[j] = dp[(j + HB_CW) % 10];
+        tq[j] = dq[(j + HB_CW) % 10];
+    }
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        dp[j] = tp[j];
+        if (!PLAIN) dq[j] = tq[j];
     }
 }
 
@@ -252,51 +263,51 @@ __global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *
     float *odst = hbuf + (((size_t)p * 3 + c) * CE_SSIM2_STREAMS + s) * plane + (size_t)(y0 + lr) * pitch + 4 * lq;
     const float *osrc = &s_out[s * HB_HALF + (4 * lq) * HB_LD + lr];
 
-    float4 pf[2][4];  // two chunks in flight
-    auto load_chunk = [&](int k, float4 (&dst)[4]) {
+    float4 pf[4];  // the next chunk, in flight
+    auto load_chunk = [&](int k) {
         if (loader) {
             const int col = max(HB_CW * k - 28 + 4 * (int)lq, 0);  // clamped: always a readable address
 #pragma unroll
-            for (int m = 0; m < 4; m++) dst[m] = *reinterpret_cast<const float4 *>(src + (size_t)(8 * m) * pitch + col);
+            for (int m = 0; m < 4; m++) pf[m] = *reinterpret_cast<const float4 *>(src + (size_t)(8 * m) * pitch + col);
         }
     };
-    auto stash_chunk = [&](int k, const float4 (&v)[4]) {
+    auto stash_chunk = [&](int k) {
         if (loader) {
             const int col = HB_CW * k - 28 + 4 * (int)lq;  // outside [0, w) the filter sees zeros
             float *dst = sdst + (k & 1) * HB_HALF;
 #pragma unroll
             for (int m = 0; m < 4; m++) {
                 const bool rv = y0 + lrow0 + 8 * m < h && col >= 0;  // col is a multiple of 4: sign is per float4
-                dst[8 * m] = (rv && col < (int)w) ? v[m].x : 0.0f;
-                dst[8 * m + HB_LD] = (rv && col + 1 < (int)w) ? v[m].y : 0.0f;
-                dst[8 * m + 2 * HB_LD] = (rv && col + 2 < (int)w) ? v[m].z : 0.0f;
-                dst[8 * m + 3 * HB_LD] = (rv && col + 3 < (int)w) ? v[m].w : 0.0f;
+                dst[8 * m] = (rv && col < (int)w) ? pf[m].x : 0.0f;
+                dst[8 * m + HB_LD] = (rv && col + 1 < (int)w) ? pf[m].y : 0.0f;
+                dst[8 * m + 2 * HB_LD] = (rv && col + 2 < (int)w) ? pf[m].z : 0.0f;
+                dst[8 * m + 3 * HB_LD] = (rv && col + 3 < (int)w) ? pf[m].w : 0.0f;
             }
         }
     };
 
-    // the half "before chunk 0" is all zero padding
-    for (uint32_t i = tid; i < 4 * HB_HALF; i += HB_THREADS) (&s_in[0][0])[i] = 0.0f;
-    load_chunk(0, pf[0]);
-    if (n_chunks > 1) load_chunk(1, pf[1]);
-    __syncthreads();
-    stash_chunk(0, pf[0]);
+    load_chunk(0);
+    stash_chunk(0);
+    if (n_chunks > 1) load_chunk(1);
     __syncthreads();
 
-    float prev[3] = {0.f, 0.f, 0.f}, prev2[3] = {0.f, 0.f, 0.f};
+    float prev[3] = {0.f, 0.f, 0.f}, prev2[3] = {0.f, 0.f, 0.f}, dp[10], dq[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) dp[j] = dq[j] = 0.0f;  // inputs before column -28 of chunk 0: zero padding
     const float *sp = &s_in[(s == 1 || s == 3) ? 1 : 0][lane];
     const float *sq = &s_in[(s == 2 || s == 0) ? 0 : 1][lane];  // a*a -> a, b*b and a*b -> b (unused when plain)
     float *so = &s_out[s * HB_HALF + lane];
 
-    // While chunk k is filtered, chunk k+1 is in flight in `nxt`; chunk k+2 is requested into `cur`,
-    // whose previous content (chunk k) is already in LDS.
-    auto hblur_iter = [&](int k, float4 (&cur)[4], const float4 (&nxt)[4]) {
-        if (k + 2 < n_chunks) load_chunk(k + 2, cur);
-        const uint32_t oc = (k & 1) * HB_HALF, oo = HB_HALF - oc;
+    // Iteration k: lay chunk k+1 (requested one iteration ago) into the half nobody reads, request chunk
+    // k+2 into the freed registers, filter chunk k, store its outputs, one barrier.
+    for (int k = 0; k < n_chunks; k++) {
+        if (k + 1 < n_chunks) stash_chunk(k + 1);
+        if (k + 2 < n_chunks) load_chunk(k + 2);
+        const uint32_t oc = (k & 1) * HB_HALF;
         if (s < 2)
-            hblur_chunk<true>(sp + oc, sp + oo, sq + oc, sq + oo, so, prev, prev2, rg);
+            hblur_chunk<true>(sp + oc, sq + oc, so, dp, dq, prev, prev2, rg);
         else
-            hblur_chunk<false>(sp + oc, sp + oo, sq + oc, sq + oo, so, prev, prev2, rg);
+            hblur_chunk<false>(sp + oc, sq + oc, so, dp, dq, prev, prev2, rg);
         // the wave stores its own tile (whole 128-byte lines)
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -304,20 +315,10 @@ __global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *
 #pragma unroll
             for (int m = 0; m < 8; m++) {
                 const float4 v = make_float4(osrc[8 * m], osrc[8 * m + HB_LD], osrc[8 * m + 2 * HB_LD], osrc[8 * m + 3 * HB_LD]);
-#if HB_ABLATE != 1
                 *reinterpret_cast<float4 *>(odst + (size_t)(8 * m) * pitch + (size_t)(HB_CW * (k - 1))) = v;
-#else
-                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#endif
             }
         }
-        lds_barrier();  // all waves are done reading the input halves
-        if (k + 1 < n_chunks) stash_chunk(k + 1, nxt);
-        lds_barrier();
-    };
-    for (int k = 0; k < n_chunks; k += 2) {
-        hblur_iter(k, pf[0], pf[1]);
-        if (k + 1 < n_chunks) hblur_iter(k + 1, pf[1], pf[0]);
+        lds_barrier();  // chunk k+1 is complete in LDS and every wave is done with chunk k's half
     }
 }
 
