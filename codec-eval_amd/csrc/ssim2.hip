@@ -341,6 +341,67 @@ constexpr int VB_PLANES = 7;                  // 5 streams + xyb(ref) + xyb(test
 constexpr int VB_SLOT = VB_G * 64;            // floats per plane per group
 constexpr int VB_GROUP = VB_PLANES * VB_SLOT; // floats per group
 
+struct vblur_state {
+    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3];
+    float rr[16][CE_SSIM2_STREAMS];  // the last 16 rows of the five streams: the left tap is 10 rows back
+    double acc[6];
+};
+
+// The four filter steps of DMA group g (ring phase GG = g mod 4, so every register-ring index is static).
+// CHECKED = false is the steady state: all four rows lie in [4, h), so nothing is masked and nothing
+// branches; CHECKED = true handles the first group (rows 0..3 only prime the filter) and the tail.
+template <int GG, bool CHECKED>
+__device__ __forceinline__ void vblur_group(vblur_state &st, const float *__restrict__ slot, int g, uint32_t h,
+                                            const rg_consts &rg)
+{
+    const float C2 = 0.0009f;
+    float gacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < VB_G; e++) {
+        const uint32_t i = (uint32_t)(4 * g + e);
+        constexpr int base = 4 * GG;
+        const int re = base + e;  // i mod 16
+        float v[CE_SSIM2_STREAMS];
+#pragma unroll
+        for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
+            const float ld = slot[s * VB_SLOT + e * 64];
+            const float right = (!CHECKED || i < h) ? ld : 0.0f;
+            const float left = st.rr[(re + 6) & 15][s];  // row i-10
+            st.rr[re][s] = right;
+            v[s] = rg_step(left + right, st.prev[s], st.prev2[s], rg);
+        }
+        if (!CHECKED || (i >= 4 && i < h + 4)) {
+            const float img1 = slot[5 * VB_SLOT + e * 64], img2 = slot[6 * VB_SLOT + e * 64];
+            const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
+            const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
+            const float mu_diff = mu1 - mu2;
+            const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
+            const float num_s = __builtin_fmaf(2.0f, s12 - mu12, C2);
+            const float denom_s = (s11 - mu11) + (s22 - mu22) + C2;
+            // The lineage widens here and pools in f64.  On the device the per-pixel terms stay f32: the SSIM
+            // ratio keeps the exact f32 divide, 1 - ratio is exact for ratio in [0.5, 2]; the edge ratio is formed
+            // as (|e2| - |e1|) * rcp(1 + |e1|) (relative error ~2e-7 instead of an f64 divide).  The six terms are
+            // summed in f32 over the 4 rows of a DMA group and only then added to the f64 accumulators.
+            float d = 1.0f - (num_m * num_s) / denom_s;
+            d = d > 0.0f ? d : 0.0f;
+            const float dd = d * d;
+            const float e1 = fabsf(img1 - mu1), e2 = fabsf(img2 - mu2);
+            const float d1 = (e2 - e1) * __builtin_amdgcn_rcpf(1.0f + e1);
+            const float artifact = d1 > 0.0f ? d1 : 0.0f;
+            const float detail = d1 < 0.0f ? -d1 : 0.0f;
+            const float aa = artifact * artifact, ll = detail * detail;
+            gacc[0] += d;
+            gacc[1] += dd * dd;
+            gacc[2] += artifact;
+            gacc[3] += aa * aa;
+            gacc[4] += detail;
+            gacc[5] += ll * ll;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) st.acc[q] += (double)gacc[q];
+}
+
 template <int LEVEL>
 __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict__ hbuf, const float *__restrict__ xyb,
                                                         const uint32_t *__restrict__ pair_ref,
@@ -374,86 +435,59 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
         __builtin_amdgcn_global_load_lds((gptr)(xb + offx), (lptr)(dst + 6 * VB_SLOT), 16, 0, 0);
     };
 
-    float prev[CE_SSIM2_STREAMS][3], prev2[CE_SSIM2_STREAMS][3], rr[16][CE_SSIM2_STREAMS];
+    vblur_state st;
 #pragma unroll
     for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) prev[s][k] = prev2[s][k] = 0.0f;
+        for (int k = 0; k < 3; k++) st.prev[s][k] = st.prev2[s][k] = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; e++) rr[e][s] = 0.0f;
+        for (int e = 0; e < 16; e++) st.rr[e][s] = 0.0f;
     }
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    const float C2 = 0.0009f;
-    const uint32_t steps = h + 4;
-    const int n_groups = (int)((steps + VB_G - 1) / VB_G);
+#pragma unroll
+    for (int q = 0; q < 6; q++) st.acc[q] = 0.0;
+    const int n_groups = (int)((h + 4 + VB_G - 1) / VB_G);
+    const int full_groups = (int)(h / VB_G);  // groups 1 .. full_groups-1 have all four rows in [4, h)
 
     issue_group(0);
     issue_group(1);
-    for (int g0 = 0; g0 < n_groups; g0 += 4) {
-#pragma unroll
-        for (int gg = 0; gg < 4; gg++) {
-            const int g = g0 + gg;
-            if (g < n_groups) {
-                // group g has landed once at most the 7 requests of group g+1 are outstanding
-                asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-                const float *slot = ring + (gg & 1) * VB_GROUP + lane;
-                float gacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < VB_G; e++) {
-                    const uint32_t i = (uint32_t)(4 * g + e);
-                    constexpr int kDummy = 0;
-                    (void)kDummy;
-                    const int re = 4 * gg + e;  // i mod 16
-                    float v[CE_SSIM2_STREAMS];
-#pragma unroll
-                    for (int s = 0; s < CE_SSIM2_STREAMS; s++) {
-                        const float ld = slot[s * VB_SLOT + e * 64];
-                        const float right = i < h ? ld : 0.0f;
-                        const float left = rr[(re + 6) & 15][s];  // row i-10
-                        rr[re][s] = right;
-                        v[s] = rg_step(left + right, prev[s], prev2[s], rg);
-                    }
-                    if (i >= 4 && i < steps) {
-                        const float img1 = slot[5 * VB_SLOT + e * 64], img2 = slot[6 * VB_SLOT + e * 64];
-                        const float mu1 = v[0], mu2 = v[1], s11 = v[2], s22 = v[3], s12 = v[4];
-                        const float mu11 = mu1 * mu1, mu22 = mu2 * mu2, mu12 = mu1 * mu2;
-                        const float mu_diff = mu1 - mu2;
-                        const float num_m = __builtin_fmaf(mu_diff, -mu_diff, 1.0f);
-                        const float num_s = __builtin_fmaf(2.0f, s12 - mu12, C2);
-                        const float denom_s = (s11 - mu11) + (s22 - mu22) + C2;
-                        // The lineage widens here and pools in f64.  On the device the per-pixel terms stay
-                        // f32 (1 - ratio is exact for ratio in [0.5, 2]; the edge ratio is formed as
-                        // (|e2| - |e1|) / (1 + |e1|), relative error ~2e-7 instead of an f64 divide), are summed
-                        // in f32 over the 4 rows of a DMA group and only then added to the f64 accumulators.
-                        float d = 1.0f - (num_m * num_s) / denom_s;
-                        d = d > 0.0f ? d : 0.0f;
-                        const float dd = d * d;
-                        const float e1 = fabsf(img1 - mu1), e2 = fabsf(img2 - mu2);
-                        const float d1 = (e2 - e1) / (1.0f + e1);
-                        const float artifact = d1 > 0.0f ? d1 : 0.0f;
-                        const float detail = d1 < 0.0f ? -d1 : 0.0f;
-                        const float aa = artifact * artifact, ll = detail * detail;
-                        gacc[0] += d;
-                        gacc[1] += dd * dd;
-                        gacc[2] += artifact;
-                        gacc[3] += aa * aa;
-                        gacc[4] += detail;
-                        gacc[5] += ll * ll;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 6; q++) acc[q] += (double)gacc[q];
-                // this group's slot is free once its LDS reads have returned; refill it with group g+2
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                issue_group(g + 2);
-            }
-        }
+    // one turn of the loop = 4 groups = 16 rows = one turn of the register ring
+#define CE_VGROUP(GG, CHECKED)                                                                         \
+    do {                                                                                               \
+        /* group g has landed once at most the 7 requests of group g+1 are outstanding */              \
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                                               \
+        vblur_group<GG, CHECKED>(st, ring + ((GG) & 1) * VB_GROUP + lane, g0 + (GG), h, rg);           \
+        /* the slot is free once its LDS reads have returned; refill it with group g+2 */              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+        issue_group(g0 + (GG) + 2);                                                                    \
+    } while (0)
+    // three loops so that the steady state is a branch-free body of its own: head (rows 0..15, the first four
+    // only prime the filter), interior turns, and the tail that runs the filter 4 rows past the image
+    int g0 = 0;
+    {
+        CE_VGROUP(0, true);
+        CE_VGROUP(1, true);
+        if (2 < n_groups) CE_VGROUP(2, true);
+        if (3 < n_groups) CE_VGROUP(3, true);
+        g0 = 4;
     }
+    for (; g0 + 3 < full_groups; g0 += 4) {
+        CE_VGROUP(0, false);
+        CE_VGROUP(1, false);
+        CE_VGROUP(2, false);
+        CE_VGROUP(3, false);
+    }
+    for (; g0 < n_groups; g0 += 4) {
+        CE_VGROUP(0, true);
+        if (g0 + 1 < n_groups) CE_VGROUP(1, true);
+        if (g0 + 2 < n_groups) CE_VGROUP(2, true);
+        if (g0 + 3 < n_groups) CE_VGROUP(3, true);
+    }
+#undef CE_VGROUP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land after the wave has retired
     double *dst = partials + ((((size_t)p * CE_MAX_SCALES + scale) * 3 + c) * max_vblocks + blockIdx.x) * 6;
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        const double sum = wave_sum(active ? acc[q] : 0.0);
+        const double sum = wave_sum(active ? st.acc[q] : 0.0);
         if (lane == 0) dst[q] = sum;
     }
 }
