@@ -129,6 +129,7 @@ _PROTOTYPES = [
     ("ce_debug_ssim2_planes", _i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
     ("ce_debug_ssim2_limit_scales", _i, [_vp, _i]),
     ("ce_debug_ssim2_averages", _i, [_vp, _u32, _dp, C.POINTER(_i)]),
+    ("ce_debug_cbrt_sweep", _i, [_vp, _u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]
 ABI_SYMBOLS = [p[0] for p in _PROTOTYPES]
 
@@ -300,6 +301,12 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ce_ctx_synchronize(self._h))
+
+    def debug_cbrt_sweep(self, first_bits: int, count: int):
+        """(mismatches, fallbacks) of the fast vs reference cube root over f32 bit patterns."""
+        mism, slow = C.c_uint64(), C.c_uint64()
+        self._check(lib().ce_debug_cbrt_sweep(self._h, first_bits, count, C.byref(mism), C.byref(slow)))
+        return mism.value, slow.value
 
     # -- leaf calls, same names / argument order as the reference
     def _leaf(self, fn, reference, test, width, height, *extra) -> float:

@@ -34,9 +34,9 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, ui
 }
 
 // ---- linear RGB -> positive XYB -----------------------------------------------------------
-// cube root: bit-trick seed and two f64 Newton steps rounded once to f32 (the msun cbrtf
+// cube root, reference form: bit-trick seed and two f64 Halley steps rounded once to f32 (the msun cbrtf
 // scheme); IEEE basic operations only, so host and device agree bit for bit.
-__device__ __forceinline__ float cbrt_f32(float x)
+__device__ __noinline__ float cbrt_f32_exact(float x)
 {
     uint32_t hx = __float_as_uint(x) & 0x7fffffffu;
     if (hx == 0) return x;
@@ -54,6 +54,35 @@ __device__ __forceinline__ float cbrt_f32(float x)
     r = T * T * T;
     T = T * (xd + xd + r) / (xd + r + r);
     return (float)T;
+}
+
+// The same f32 result without the two f64 divisions (they are ~2/3 of the front end's instructions).
+// Both this and the reference form compute an f64 value T within 2^-45 (relative) of the true cube root
+// and round it once to f32, so they can only differ when T lies within 2^-45 of an f32 rounding boundary.
+// The fast form: seed s = exp2(log2(x)/3) (hardware transcendentals, ~2^-21), then with d = (s^3-x)/s^3
+//     cbrt(x) = s (1-d)^(1/3) = s (1 - d/3 - d^2/9 - O(d^3)),   |d| < 2^-19, so the cubic term is < 2^-59;
+// 1/s^3 comes from v_rcp_f32 plus one f64 Newton step.  If T is closer than 2^-39 (64x the bound) to a
+// rounding boundary - about one input in 2^14 - the reference form is evaluated instead.
+// tests/test_gpu_parity.py sweeps every positive normal f32 through both forms (ce_debug_cbrt_sweep).
+__device__ __forceinline__ float cbrt_f32(float x, uint32_t *slow = nullptr)
+{
+    if (x >= 1.0e-30f && x <= 1.0e30f) {
+        const float s = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * 0.333333343f);
+        const double S = (double)s, xd = (double)x;
+        const double s3 = S * S * S;
+        const double diff = s3 - xd;
+        const double inv0 = (double)__builtin_amdgcn_rcpf((float)s3);
+        const double e = __builtin_fma(-s3, inv0, 1.0);
+        const double inv = __builtin_fma(inv0, e, inv0);
+        const double d = diff * inv;
+        const double poly = __builtin_fma(d, 1.0 / 9.0, 1.0 / 3.0) * d;
+        const double T = __builtin_fma(-S, poly, S);
+        // the low 29 mantissa bits of T are its position between two adjacent f32 values; the boundary is 2^28
+        const int32_t low = (int32_t)((uint32_t)__double2loint(T) & 0x1fffffffu) - 0x10000000;
+        if ((low < 0 ? -low : low) >= 0x4000) return (float)T;
+    }
+    if (slow) *slow += 1;
+    return cbrt_f32_exact(x);
 }
 
 #define K_M00 0.30f
@@ -492,6 +521,21 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
     }
 }
 
+// debug: every f32 bit pattern in [first, first+count) through both cube-root forms
+__global__ __launch_bounds__(256) void k_cbrt_sweep(uint32_t first, uint64_t count, unsigned long long *out)
+{
+    uint64_t mism = 0, slow = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(first + (uint32_t)i);
+        uint32_t sl = 0;
+        const float a = cbrt_f32(x, &sl), b = cbrt_f32_exact(x);
+        mism += __float_as_uint(a) != __float_as_uint(b);
+        slow += sl;
+    }
+    if (mism) atomicAdd(out, (unsigned long long)mism);
+    if (slow) atomicAdd(out + 1, (unsigned long long)slow);
+}
+
 __constant__ double c_weight[108] = {
     0.0, 0.0007376606707406586, 0.0, 0.0, 0.0007793481682867309, 0.0, 0.0, 0.0004371155730107379, 0.0, 1.1041726426657346, 0.00066284834129271, 0.00015231632783718752,
     0.0, 0.0016406437456599754, 0.0, 1.8422455520539298, 11.441172603757666, 0.0, 0.0007989109436015163, 0.000176816438078653, 0.0, 1.8787594979546387, 10.94906990605142, 0.0,
@@ -654,5 +698,19 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     CE_LAUNCH(ctx, "ssim2_finalize", k_ssim2_finalize, dim3(n_pairs), dim3(128), 0, b->d_partials, b->d_avg,
               b->d_scores, (uint32_t)levels, b->max_vblocks, g);
     CE_HIP(ctx, hipGetLastError());
+    return CE_OK;
+}
+
+int ce_ssim2_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path)
+{
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    CE_HIP(ctx, hipMalloc(&d, sizeof(h)));
+    CE_HIP(ctx, hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
+    CE_LAUNCH(ctx, "cbrt_sweep", k_cbrt_sweep, dim3(4096), dim3(256), 0, first_bits, count, d);
+    CE_HIP(ctx, hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CE_HIP(ctx, hipFree(d));
+    if (mismatches) *mismatches = h[0];
+    if (slow_path) *slow_path = h[1];
     return CE_OK;
 }

@@ -190,6 +190,11 @@ int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float 
 int ce_debug_ssim2_limit_scales(ce_batch *b, int max_scales);
 /* avg[scale][c][6] of pair `pair_index` from the last run (ssim l1,l4, artifact l1,l4, detail l1,l4) */
 int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg /* [6][3][6] */, int *n_scales);
+/* The XYB front end's cube root has a division-free fast form that falls back to the reference form
+ * (msun cbrtf: two f64 Halley steps) near f32 rounding boundaries.  This runs the f32 bit patterns
+ * [first_bits, first_bits + count) through both on the device and reports how many results differ
+ * (must be 0) and how many inputs took the fallback. */
+int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path);
 
 #ifdef __cplusplus
 }

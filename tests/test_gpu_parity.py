@@ -152,6 +152,24 @@ def test_ssim2_planes_bit_exact(gpu_ctx, oracle, ce, workloads):
 SHAPES = [(8, 8), (9, 15), (16, 8), (33, 17), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512), (512, 768)]
 
 
+@pytest.mark.gpu
+def test_ssim2_cbrt_fast_form_is_exact(gpu_ctx):
+    """The division-free cube root of the XYB front end must give the reference form's f32 for EVERY
+    positive normal input (0x00800000 .. 0x7f7fffff), and take the fallback only rarely in the
+    range the front end feeds it (mixed absorbance + bias lies in [0.0037, ~1.1])."""
+    first, last = 0x00800000, 0x7F7FFFFF
+    mism, slow = gpu_ctx.debug_cbrt_sweep(first, last - first + 1)
+    assert mism == 0
+    lo, hi = 0x3B000000, 0x3FC00000  # [2^-9, 1.5)
+    mism, slow = gpu_ctx.debug_cbrt_sweep(lo, hi - lo)
+    assert mism == 0
+    assert slow / (hi - lo) < 2.5e-4  # ~2^-14 expected
+    # zero, subnormals, huge values, negatives and NaN patterns go through the reference form itself
+    for a, n in ((0, 0x00800000), (0x7F000000, 0x01000000), (0x80000000, 0x01000000)):
+        mism, slow = gpu_ctx.debug_cbrt_sweep(a, n)
+        assert mism == 0
+
+
 @pytest.mark.parametrize("w,h", SHAPES)
 def test_ssim2_parity_shapes(gpu_ctx, oracle, ce, workloads, w, h):
     ref = workloads.make_reference(w, h, 100 + w)
