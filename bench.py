@@ -46,6 +46,8 @@ def parse():
                     help="BASELINE.json configs[] entry, 1-based (default 2 = the headline workload). "
                          "3/4/5 are extra measurements, scaled down with --refs")
     ap.add_argument("--refs", type=int, default=0, help="override the number of reference images (configs 3-5)")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="batches in flight per shape bucket (1 = launch and collect each step before the next)")
     return ap.parse_args()
 
 
@@ -106,32 +108,50 @@ def main():
         cfg = ce.MetricConfig.all().with_xyb_roundtrip()
         workload = f"BASELINE configs[4]: {n} 512x512 refs x 25 qualities x {{4:4:4, 4:2:0}}, all metrics, XYB roundtrip on"
 
-    # one context (= one HIP stream family) per shape bucket, so the buckets' kernel chains overlap on the GPU
-    ctxs = [ce.Context(local_rank) for _ in grids]
+    # One context (= one HIP stream family) per shape bucket, so the buckets' kernel chains overlap on the GPU.
+XX
+    # collected, the way EvalSession streams a corpus that is larger than one batch.  Every timed step's scores
+    # are collected inside the timed region.
+    depth = max(1, args.depth)
+    sets = []
+    for _ in range(depth):
+        cs = [ce.Context(local_rank) for _ in grids]
+        bs = []
+        for g, c in zip(grids, cs):
+            b = ce.Batch(c, g.width, g.height, len(g.references), len(g.pairs))
+            for i, r in enumerate(g.references):
+                b.set_reference(i, r)
+            for k, (ri, t) in enumerate(g.pairs):
+                b.set_test(k, ri, t)
+            bs.append((g, b))
+        sets.append((cs, bs))
+    ctxs, batches = sets[0]
     ctx = ctxs[0]
-    batches = []
-    for g, c in zip(grids, ctxs):
-        b = ce.Batch(c, g.width, g.height, len(g.references), len(g.pairs))
-        for i, r in enumerate(g.references):
-            b.set_reference(i, r)
-        for k, (ri, t) in enumerate(g.pairs):
-            b.set_test(k, ri, t)
-        batches.append((g, b))
     pairs_per_step = sum(len(g.pairs) for g in grids)
     mp_per_step = sum(g.megapixels for g in grids)
 
-    def step():
-        for g, b in batches:
+    def launch(k):
+        for g, b in sets[k % depth][1]:
             b.launch(len(g.pairs), cfg)
-        return [b.collect(len(g.pairs)) for g, b in batches]
 
-    for _ in range(args.warmup):
-        step()
+    def collect(k):
+        return [b.collect(len(g.pairs)) for g, b in sets[k % depth][1]]
+
+    def run_steps(n):
+        out = None
+        for k in range(n):
+            launch(k)
+            if k >= depth - 1:
+                out = collect(k - (depth - 1))
+        for k in range(max(0, n - (depth - 1)), n):
+            out = collect(k)
+        return out
+
+    run_steps(args.warmup)
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        scores = step()
+    scores = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -257,6 +277,7 @@ def main():
                 "metrics": [m for m in ("dssim", "ssimulacra2", "butteraugli", "psnr") if getattr(cfg, m)],
                 "sharding": "by reference image, one process + one HIP stream per GPU, no collective",
                 "inputs": "resident in HBM (uploaded before the timed region)",
+                "batches_in_flight": depth,
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
@@ -265,10 +286,11 @@ def main():
         }
         print(json.dumps(line), flush=True)
 
-    for _, b in batches:
-        b.close()
-    for c in ctxs:
-        c.close()
+    for cs, bs in sets:
+        for _, b in bs:
+            b.close()
+        for c in cs:
+            c.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -19,7 +19,7 @@ from typing import Iterable, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libce_metrics_hip.so")
+LIB_PATH = os.environ.get("CE_METRICS_LIB") or os.path.join(_HERE, "libce_metrics_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 # ---- enums of include/ce_metrics.h ---------------------------------------------------------
