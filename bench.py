@@ -109,9 +109,10 @@ def main():
         workload = f"BASELINE configs[4]: {n} 512x512 refs x 25 qualities x {{4:4:4, 4:2:0}}, all metrics, XYB roundtrip on"
 
     # One context (= one HIP stream family) per shape bucket, so the buckets' kernel chains overlap on the GPU.
-XX
-    # collected, the way EvalSession streams a corpus that is larger than one batch.  Every timed step's scores
-    # are collected inside the timed region.
+    # `--depth` > 1 keeps that many sets of batches in flight (step k is launched before step k-1's scores are
+    # collected, the way EvalSession streams a corpus larger than one batch); every timed step's scores are
+    # still collected inside the timed region.  Measured: no gain on this workload (the GPU is already busy),
+    # so the default is 1.
     depth = max(1, args.depth)
     sets = []
     for _ in range(depth):
