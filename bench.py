@@ -14,7 +14,7 @@ N > 1: the grid shards by reference image with no data-path collective; every ra
 Kodak-24-shaped corpus (different seeds), i.e. per-GPU work is fixed => "scaling": "weak".
 torch.distributed (RCCL) is used only for the barriers and the max-over-ranks of the time.
 
-Extra JSON objects: "roofline" (dominant kernel, HIP-event timed live) and "cpu_baseline"
+Extra JSON objects: "roofline" (dominant kernel, HIP-event timed in the timed region) and "cpu_baseline"
 (the C oracle timed on this host's cores, rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -46,6 +46,9 @@ def parse():
                     help="BASELINE.json configs[] entry, 1-based (default 2 = the headline workload). "
                          "3/4/5 are extra measurements, scaled down with --refs")
     ap.add_argument("--refs", type=int, default=0, help="override the number of reference images (configs 3-5)")
+    ap.add_argument("--no-events", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
+    ap.add_argument("--one-context", action="store_true", help="all shape buckets on one context (buckets run back to back)")
+    ap.add_argument("--solo", action="store_true", help="extra pass: time every kernel alone on one stream")
     ap.add_argument("--depth", type=int, default=1,
                     help="batches in flight per shape bucket (1 = launch and collect each step before the next)")
     return ap.parse_args()
@@ -117,6 +120,8 @@ def main():
     sets = []
     for _ in range(depth):
         cs = [ce.Context(local_rank) for _ in grids]
+        if args.one_context:
+            cs = [cs[0]] * len(grids)
         bs = []
         for g, c in zip(grids, cs):
             b = ce.Batch(c, g.width, g.height, len(g.references), len(g.pairs))
@@ -148,7 +153,17 @@ def main():
             out = collect(k)
         return out
 
+    # Per-kernel HIP events are recorded IN the timed region, each pair on the stream its kernel is launched on
+    # and with the batch's normal multi-stream schedule (prof mode 2): the durations are what rocprofv3's kernel
+    # trace of this same command reports (profiles/).  --no-events switches them off (A/B: no measurable cost).
+    events = not args.no_events
+    all_ctxs = list({id(c): c for cs, _ in sets for c in cs}.values())
+    for c in all_ctxs:
+        c.prof_enable(events, serial=False)
+
     run_steps(args.warmup)
+    for c in all_ctxs:
+        c.prof_reset()
 
     barrier()
     t0 = time.perf_counter()
@@ -167,23 +182,35 @@ def main():
     value = total_mp / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- roofline: per-kernel HIP-event timing of the same steps (separate pass: events perturb) ----
+    def gather_stats():
+        acc = {}
+        for c in all_ctxs:
+            for k, (n, ms) in c.prof_stats().items():
+                n0, ms0 = acc.get(k, (0, 0.0))
+                acc[k] = (n0 + n, ms0 + ms)
+        return acc
+
+    # ---- roofline: the dominant kernel of the timed region --------------------------------------
     roofline = None
-    kernels = {}
-    if rank == 0:
+    kernels = gather_stats() if events else {}
+    for c in all_ctxs:
+        c.prof_enable(False)
+    solo = {}
+    if rank == 0 and args.solo:
+        # optional extra pass: one kernel at a time on one stream ("solo" durations, no sharing of the GPU)
         for c in ctxs:
             c.prof_reset()
-            c.prof_enable(True)
+            c.prof_enable(True, serial=True)
         for _ in range(args.steps):
-            for g, b in batches:  # one bucket at a time and one stream each: kernel times must not overlap
+            for g, b in batches:
                 b.launch(len(g.pairs), cfg)
                 b.collect(len(g.pairs))
-        kernels = {}
         for c in ctxs:
-            c.prof_enable(False)
             for k, (n, ms) in c.prof_stats().items():
-                n0, ms0 = kernels.get(k, (0, 0.0))
-                kernels[k] = (n0 + n, ms0 + ms)
+                n0, ms0 = solo.get(k, (0, 0.0))
+                solo[k] = (n0 + n, ms0 + ms)
+            c.prof_enable(False)
+    if rank == 0 and kernels:
         total_ms = sum(ms for _, ms in kernels.values())
         name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
         px0 = sum(len(g.pairs) * g.width * g.height for g in grids)  # scale-0 pixels per step
@@ -209,13 +236,18 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": launches,
+            "timing": "HIP events on the launch stream, in the timed region; kernels of other pyramid levels and of "
+                      "the other shape bucket run concurrently on other streams",
             "kernel_share_of_gpu_time": round(ms / total_ms, 3),
-            # the whole metric against the same peak: 210 B per scale-0 pixel over the TIMED
-            # step (levels and shape buckets overlap on separate streams there, so this is not the kernel sum)
+            # the whole metric against the same peak: 210 B per scale-0 pixel over the timed step
             "pipeline_achieved": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9, 1),
             "pipeline_frac": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "serial_kernel_ms_per_step": round(total_ms / args.steps, 4),
         }
+        if solo:
+            sn, sms = solo[name]
+            roofline["solo_avg_launch_ms"] = round(sms / sn, 4)
+            roofline["solo_frac"] = round(bytes_per_launch / (sms / sn * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            roofline["solo_kernel_ms_per_step"] = round(sum(m for _, m in solo.values()) / args.steps, 4)
 
     # ---- CPU baseline: the C oracle on this host's cores (rank 0, N = 1 only) -------------------
     cpu_baseline = None
@@ -284,13 +316,14 @@ def main():
             "cpu_baseline": cpu_baseline,
             "max_rel_dev_vs_oracle": max_dev,
             "kernels_ms_per_step": {k: round(ms / args.steps, 4) for k, (n, ms) in sorted(kernels.items())},
+            "solo_kernels_ms_per_step": {k: round(ms / args.steps, 4) for k, (n, ms) in sorted(solo.items())} or None,
         }
         print(json.dumps(line), flush=True)
 
     for cs, bs in sets:
         for _, b in bs:
             b.close()
-        for c in cs:
+        for c in {id(c): c for c in cs}.values():
             c.close()
     if dist is not None:
         dist.destroy_process_group()

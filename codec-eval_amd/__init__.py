@@ -374,8 +374,10 @@ class Context:
         return list(out)
 
     # -- measurement hooks
-    def prof_enable(self, on: bool = True):
-        self._check(lib().ce_prof_enable(self._h, 1 if on else 0))
+    def prof_enable(self, on=True, serial: bool = True):
+        """Per-kernel HIP-event timing.  serial=True: one kernel at a time on the context's stream (solo
+        times); serial=False: keep the batch's multi-stream schedule (times as rocprofv3 sees them)."""
+        self._check(lib().ce_prof_enable(self._h, 0 if not on else (1 if serial else 2)))
 
     def prof_reset(self):
         self._check(lib().ce_prof_reset(self._h))

@@ -625,6 +625,7 @@ int ce_prof_enable(ce_ctx *ctx, int on)
     if (!ctx) return CE_ERR_INVALID_ARG;
     prof_drain(ctx);
     ctx->prof = on != 0;
+    ctx->prof_serial = on == 1;
     return CE_OK;
 }
 

@@ -51,7 +51,8 @@ struct ce_ctx {
     float *d_xyb_thresh = nullptr; // linear->sRGB u8 decision thresholds (xyb.rs:86-88)
 
     // profiling
-    bool prof = false;
+    bool prof = false;         // record a HIP event pair around every launch (on the launch's own stream)
+    bool prof_serial = false;  // ...and keep everything on the context's stream so kernel times do not overlap
     std::vector<ce_kernel_stat> stats;
     struct pending { int stat; hipEvent_t e0, e1; };
     std::vector<pending> pend;

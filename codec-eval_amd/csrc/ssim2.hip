@@ -665,7 +665,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     const int levels = std::min(b->n_scales, b->debug_max_scales);
     // Front end on the context's stream (level s+1 needs level s's linear planes); each level's row and
     // column pass on that level's own stream, so the small, latency-bound levels overlap the large ones.
-    // Under profiling everything stays on one stream so that per-kernel times do not overlap.
+    // In the serial profiling mode everything stays on one stream so that per-kernel times do not overlap.
     for (int s = 0; s < levels; s++) {
         const ce_scale_dims &d = b->sd[s];
         const bool has_next = s + 1 < levels;
@@ -679,7 +679,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             CE_LAUNCH(ctx, "ssim2_prep", k_ssim2_prep<false>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
                       (const float *)b->d_lin[s], b->d_xyb[s], b->d_lin[has_next ? s + 1 : s], d.w, d.h, d.pitch, d.plane,
                       nd.pitch, nd.plane, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
-        hipStream_t ls = ctx->prof ? ctx->stream : b->lvl_stream[s];
+        hipStream_t ls = ctx->prof_serial ? ctx->stream : b->lvl_stream[s];
         if (ls != ctx->stream) {
             CE_HIP(ctx, hipEventRecord(b->ev_prep[s], ctx->stream));
             CE_HIP(ctx, hipStreamWaitEvent(ls, b->ev_prep[s], 0));
@@ -693,7 +693,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         g.npix[s] = d.w * d.h;
         g.nblk[s] = nblk;
     }
-    if (!ctx->prof)
+    if (!ctx->prof_serial)
         for (int s = 0; s < levels; s++) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[s], 0));
     CE_LAUNCH(ctx, "ssim2_finalize", k_ssim2_finalize, dim3(n_pairs), dim3(128), 0, b->d_partials, b->d_avg,
               b->d_scores, (uint32_t)levels, b->max_vblocks, g);

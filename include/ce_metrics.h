@@ -169,8 +169,11 @@ int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t m
 void ce_ref_destroy(ce_ref *ref);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------ */
-/* Bracket every kernel launch with HIP events on the context's stream and accumulate
- * per-kernel time.  Off by default (events perturb back-to-back launches). */
+/* Bracket every kernel launch with a HIP event pair, recorded on the stream the kernel is launched on,
+ * and accumulate per-kernel time.  on = 0: off (default).  on = 2: events only; the batch keeps its
+ * multi-stream schedule, so a kernel's time includes whatever it shares the GPU with (what rocprofv3's
+ * kernel trace sees).  on = 1: additionally keep all launches on the context's stream, one kernel at a
+ * time ("solo" times). */
 int ce_prof_enable(ce_ctx *ctx, int on);
 int ce_prof_reset(ce_ctx *ctx);
 /* number of distinct kernels seen; then per index: name, launches, total ms */
