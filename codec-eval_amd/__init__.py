@@ -84,6 +84,13 @@ def _raise(status: int, message: str):
     raise CodecEvalError(status, message)
 
 
+def _error_obj(status: int, message: str) -> CodecEvalError:
+    try:
+        _raise(status, message)
+    except CodecEvalError as e:
+        return e
+
+
 _lib: Optional[C.CDLL] = None
 
 # (name, restype, argtypes) — must list every function include/ce_metrics.h declares
@@ -119,6 +126,7 @@ _PROTOTYPES = [
     ("ce_batch_butteraugli_pnorm3", _i, [_vp, _u32, _dp]),
     ("ce_ref_create", _i, [_vp, _u8p, _sz, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("ce_ref_compare", _i, [_vp, _u8p, _sz, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_ref_compare_many", _i, [_vp, C.POINTER(_u8p), C.POINTER(_sz), _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_ref_destroy", None, [_vp]),
     ("ce_prof_enable", _i, [_vp, _i]),
     ("ce_prof_reset", _i, [_vp]),
@@ -493,6 +501,22 @@ class ReferenceHandle:
         self.ctx._check(lib().ce_ref_compare(self._h, t.ctypes.data, t.size, config.mask, intensity_target, C.byref(s)))
         return MetricResult.from_c(s)
 
+    def compare_many(self, tests, config: MetricConfig = None, intensity_target: float = DEFAULT_INTENSITY_TARGET):
+        """The quality sweep of this reference in one launch; returns one MetricResult (or error) per test."""
+        config = config or MetricConfig.ssimulacra2_only()
+        bufs = [_buf(t) for t in tests]
+        n = len(bufs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = (_sz * n)(*[b.size for b in bufs])
+        out = (CeScores * n)()
+        self.ctx._check(lib().ce_ref_compare_many(self._h, ptrs, lens, n, config.mask, intensity_target, out))
+        res = []
+        for s in out:
+            res.append(MetricResult.from_c(s) if s.status == 0 else _error_obj(s.status, self.ctx._err()))
+        return res
+
     def close(self):
         if self._h and self.ctx._h:
             lib().ce_ref_destroy(self._h)
@@ -503,6 +527,49 @@ class ReferenceHandle:
             self.close()
         except Exception:
             pass
+
+
+# ---- codec-iter's plug point (crates/codec-iter/src/eval.rs:56-92, gpu.rs:21-134) ------------
+Ssimulacra2Reference = ReferenceHandle  # fast_ssim2::Ssimulacra2Reference::{new, compare}
+
+
+class GpuSsim2:
+    """GpuSsim2::new(w, h) / compute(&mut self, reference, distorted) (gpu.rs:40-116): fixed shape, packed
+    RGB8 from host memory, one call in flight per object."""
+
+    def __init__(self, width: int, height: int, device: int = 0):
+        self.ctx = Context(device)
+        self.width, self.height = int(width), int(height)
+
+    def compute(self, reference, distorted) -> float:
+        r, d = _buf(reference), _buf(distorted)
+        expected = self.width * self.height * 3
+        if r.size != expected or d.size != expected:  # gpu.rs:84-94
+            raise RuntimeError(f"Image size mismatch: expected {expected} bytes ({self.width}x{self.height}x3), "
+                               f"got ref={r.size} dis={d.size}")
+        return self.ctx.calculate_ssimulacra2(r, d, self.width, self.height)
+
+    def dimensions(self):
+        return (self.width, self.height)
+
+    def close(self):
+        self.ctx.close()
+
+
+class Ssim2Backend:
+    """eval.rs:56-92.  The reference's enum has a Gpu and a Cpu arm; this package is the device arm and has
+    no CPU path, so only that arm exists here."""
+
+    def __init__(self, gpu: GpuSsim2):
+        self.gpu = gpu
+
+    def compare_with_precomputed(self, source, decoded, reference: Optional[ReferenceHandle], image_name: str, quality: int) -> float:
+        try:
+            if reference is not None:
+                return reference.compare(decoded).ssimulacra2
+            return self.gpu.compute(source, decoded)
+        except (CodecEvalError, RuntimeError) as e:  # eval.rs:88
+            raise RuntimeError(f"SSIM2 error for {image_name} q{quality}: {e}") from e
 
 
 # ---- eval helpers (src/eval/helpers.rs) ----------------------------------------------------

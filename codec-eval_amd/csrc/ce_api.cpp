@@ -262,6 +262,8 @@ int ce_batch_set_reference(ce_batch *b, uint32_t ref_index, const uint8_t *rgb, 
     if (len != b->img_bytes)
         return fail(b->ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(b->img_bytes) +
                                                     " bytes, got " + std::to_string(len));
+    b->ssim2_ref_src = nullptr;  // cached reference-side planes are stale
+    b->refs_rt_valid = false;
     return upload(b, b->d_refs + (size_t)ref_index * b->img_bytes, rgb);
 }
 
@@ -288,7 +290,13 @@ int ce_batch_set_test(ce_batch *b, uint32_t pair_index, uint32_t ref_index, cons
     return upload(b, b->d_tests + (size_t)pair_index * b->img_bytes, rgb);
 }
 
-void *ce_batch_reference_slab(ce_batch *b) { return b ? b->d_refs : nullptr; }
+void *ce_batch_reference_slab(ce_batch *b)
+{
+    if (!b) return nullptr;
+    b->ssim2_ref_src = nullptr;  // the caller may overwrite references behind our back
+    b->refs_rt_valid = false;
+    return b->d_refs;
+}
 void *ce_batch_test_slab(ce_batch *b) { return b ? b->d_tests : nullptr; }
 
 int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags, float intensity_target)
@@ -312,8 +320,11 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     if (flags & CE_FLAG_XYB_ROUNDTRIP) {
         // MetricConfig::xyb_roundtrip: every metric sees the roundtripped reference (session.rs:447-456)
         if (!b->d_refs_rt) CE_HIP(ctx, hipMalloc(&b->d_refs_rt, b->img_bytes * b->max_refs + 16));
-        int rc = ce_launch_xyb_roundtrip(ctx, b->d_refs, b->d_refs_rt, (size_t)n_refs_used * b->w * b->h);
-        if (rc != CE_OK) return rc;
+        if (!(b->keep_ref_pyramid && b->refs_rt_valid)) {
+            int rc = ce_launch_xyb_roundtrip(ctx, b->d_refs, b->d_refs_rt, (size_t)n_refs_used * b->w * b->h);
+            if (rc != CE_OK) return rc;
+            b->refs_rt_valid = true;
+        }
         d_refs = b->d_refs_rt;
     }
     if (metric_mask & CE_METRIC_PSNR) {
@@ -592,7 +603,56 @@ int ce_ref_create(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, u
         ce_batch_destroy(b);
         return rc;
     }
+    b->keep_ref_pyramid = true;
     *out = new ce_ref{ctx, b, flags};
+    return CE_OK;
+}
+
+int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *test_lens, uint32_t n_tests,
+                        uint32_t metric_mask, float intensity_target, ce_scores *out)
+{
+    if (!ref || !tests || !test_lens || !out) return CE_ERR_INVALID_ARG;
+    if (n_tests == 0) return CE_OK;
+    ce_ctx *ctx = ref->ctx;
+    ce_batch *b = ref->batch;
+    if (n_tests > b->max_pairs) {
+        // grow the handle: a new batch of the same shape takes over the resident reference (device copy)
+        ce_batch *nb = nullptr;
+        int rc = ce_batch_create(ctx, b->w, b->h, 1, n_tests, &nb);
+        if (rc != CE_OK) return rc;
+        CE_HIP(ctx, hipMemcpyAsync(nb->d_refs, b->d_refs, b->img_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        nb->keep_ref_pyramid = true;
+        ce_batch_destroy(b);
+        ref->batch = b = nb;
+    }
+    bool any_ok = false;
+    for (uint32_t i = 0; i < n_tests; i++) {
+        out[i] = ce_scores{};
+        if (!tests[i]) return CE_ERR_INVALID_ARG;
+        if (test_lens[i] != b->img_bytes) {
+            out[i].status = fail(ctx, CE_ERR_DIM_MISMATCH, "Dimension mismatch: reference " + std::to_string(b->img_bytes) +
+                                                               " bytes, test " + std::to_string(test_lens[i]) + " bytes");
+            continue;
+        }
+        any_ok = true;
+    }
+    if (!any_ok) return CE_OK;
+    // Rejected items keep their slot (their scores are discarded); every valid test is uploaded to its own slot.
+    std::vector<ce_scores> tmp(n_tests);
+    for (uint32_t i = 0; i < n_tests; i++) {
+        if (out[i].status != CE_OK) {
+            int rc = ce_batch_bind_pair(b, i, 0);
+            if (rc != CE_OK) return rc;
+            continue;
+        }
+        int rc = ce_batch_set_test(b, i, 0, tests[i], test_lens[i]);
+        if (rc != CE_OK) return rc;
+    }
+    int rc = ce_batch_run(b, n_tests, metric_mask, ref->flags, intensity_target, tmp.data());
+    if (rc != CE_OK) return rc;
+    for (uint32_t i = 0; i < n_tests; i++)
+        if (out[i].status == CE_OK) out[i] = tmp[i];
     return CE_OK;
 }
 
@@ -600,13 +660,7 @@ int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t m
                    ce_scores *out)
 {
     if (!ref || !test || !out) return CE_ERR_INVALID_ARG;
-    ce_batch *b = ref->batch;
-    if (test_len != b->img_bytes)
-        return fail(ref->ctx, CE_ERR_DIM_MISMATCH, "Dimension mismatch: reference " + std::to_string(b->img_bytes) +
-                                                        " bytes, test " + std::to_string(test_len) + " bytes");
-    int rc = ce_batch_set_test(b, 0, 0, test, test_len);
-    if (rc != CE_OK) return rc;
-    rc = ce_batch_run(b, 1, metric_mask, ref->flags, intensity_target, out);
+    int rc = ce_ref_compare_many(ref, &test, &test_len, 1, metric_mask, intensity_target, out);
     if (rc != CE_OK) return rc;
     return out->status;
 }

@@ -92,6 +92,13 @@ struct ce_batch {
     ce_dev_scores *d_scores = nullptr;
     ce_dev_scores *h_scores = nullptr;  // pinned
     bool ssim2_ready = false;
+    // reference handles (ce_ref_*): the references' XYB pyramid of the last SSIMULACRA2 run stays valid
+    // until a reference is replaced, so later compares only build the distorted side
+    bool keep_ref_pyramid = false;
+    const uint8_t *ssim2_ref_src = nullptr;  // reference slab the cached pyramid was built from
+    uint32_t ssim2_ref_count = 0;            // ...and how many references it covers
+    int ssim2_ref_levels = 0;
+    bool refs_rt_valid = false;              // d_refs_rt holds the XYB roundtrip of the current references
     int debug_max_scales = CE_MAX_SCALES;  // test hook: stop the pyramid early
 
     // DSSIM working set (dssim.hip); planes are [slot][3][plane] with the level's own geometry

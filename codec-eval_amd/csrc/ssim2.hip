@@ -124,14 +124,14 @@ __global__ __launch_bounds__(256) void k_ssim2_prep(const uint8_t *__restrict__ 
                                                     float *__restrict__ xyb, float *__restrict__ lin_out, uint32_t w,
                                                     uint32_t h, uint32_t pitch, size_t plane, uint32_t opitch,
                                                     size_t oplane, int has_next, size_t img_bytes, uint32_t n_refs_used,
-                                                    uint32_t max_refs)
+                                                    uint32_t max_refs, uint32_t z0)
 {
     __shared__ float s_lut[256];
     if (FROM_U8) {
         s_lut[threadIdx.x] = lut[threadIdx.x];
         __syncthreads();
     }
-    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);  // z0 > 0: references are cached
     const uint32_t qx = blockIdx.x * 64 + (threadIdx.x & 63), qy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (qx >= (w + 1) / 2 || qy >= (h + 1) / 2) return;
     const uint8_t *src8 = nullptr;
@@ -649,6 +649,11 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     rg_consts rg;
     ce_ssim2_recursive_gaussian(rg.mul_in, rg.mul_prev);
     const uint32_t n_slots = n_refs_used + n_pairs;
+    // Ssimulacra2Reference semantics (crates/codec-iter/src/eval.rs:138-149): a reference handle keeps the
+    // references' XYB pyramid between compares, so the front end then only runs over the distorted slots
+    const bool cached = b->keep_ref_pyramid && b->ssim2_ref_src == d_refs && b->ssim2_ref_count >= n_refs_used &&
+                        b->ssim2_ref_levels == std::min(b->n_scales, b->debug_max_scales);
+    const uint32_t z0 = cached ? n_refs_used : 0;
     static const char *const kHName[CE_MAX_SCALES] = {"ssim2_hblur_L0", "ssim2_hblur_L1", "ssim2_hblur_L2",
                                                       "ssim2_hblur_L3", "ssim2_hblur_L4", "ssim2_hblur_L5"};
     static const char *const kVName[CE_MAX_SCALES] = {"ssim2_vblur_ssim_L0", "ssim2_vblur_ssim_L1", "ssim2_vblur_ssim_L2",
@@ -670,15 +675,15 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         const ce_scale_dims &d = b->sd[s];
         const bool has_next = s + 1 < levels;
         const ce_scale_dims &nd = b->sd[has_next ? s + 1 : s];
-        const dim3 quad_grid(((d.w + 1) / 2 + 63) / 64, ((d.h + 1) / 2 + 3) / 4, n_slots);
+        const dim3 quad_grid(((d.w + 1) / 2 + 63) / 64, ((d.h + 1) / 2 + 3) / 4, n_slots - z0);
         if (s == 0)
             CE_LAUNCH(ctx, "ssim2_prep_u8", k_ssim2_prep<true>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
                       (const float *)nullptr, b->d_xyb[0], b->d_lin[1], d.w, d.h, d.pitch, d.plane, nd.pitch, nd.plane,
-                      has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
+                      has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs, z0);
         else
             CE_LAUNCH(ctx, "ssim2_prep", k_ssim2_prep<false>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
                       (const float *)b->d_lin[s], b->d_xyb[s], b->d_lin[has_next ? s + 1 : s], d.w, d.h, d.pitch, d.plane,
-                      nd.pitch, nd.plane, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs);
+                      nd.pitch, nd.plane, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs, z0);
         hipStream_t ls = ctx->prof_serial ? ctx->stream : b->lvl_stream[s];
         if (ls != ctx->stream) {
             CE_HIP(ctx, hipEventRecord(b->ev_prep[s], ctx->stream));
@@ -695,6 +700,11 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     }
     if (!ctx->prof_serial)
         for (int s = 0; s < levels; s++) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[s], 0));
+    if (b->keep_ref_pyramid && !cached) {
+        b->ssim2_ref_src = d_refs;
+        b->ssim2_ref_count = n_refs_used;
+        b->ssim2_ref_levels = levels;
+    }
     CE_LAUNCH(ctx, "ssim2_finalize", k_ssim2_finalize, dim3(n_pairs), dim3(128), 0, b->d_partials, b->d_avg,
               b->d_scores, (uint32_t)levels, b->max_vblocks, g);
     CE_HIP(ctx, hipGetLastError());

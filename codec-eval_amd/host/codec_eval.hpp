@@ -311,6 +311,102 @@ private:
     std::vector<CodecEntry> codecs_;
 };
 
+// ---- crates/codec-iter: the SSIMULACRA2 plug point ---------------------------------------------------------
+// Ssimulacra2Reference::{new, compare} (fast-ssim2; used at crates/codec-iter/src/eval.rs:138-149,83-89 and
+// crates/codec-compare/src/brute_force_sweep.rs:197-201,256): the source image is uploaded once and its
+// reference-side state stays on the device for the whole quality sweep.
+class Ssimulacra2Reference {
+public:
+    Ssimulacra2Reference(std::shared_ptr<HipBackend> be, const std::vector<uint8_t> &rgb, size_t width, size_t height)
+        : be_(std::move(be)), w_(width), h_(height)
+    {
+        const int rc = ce_ref_create(be_->ctx(), rgb.data(), rgb.size(), (uint32_t)width, (uint32_t)height, 0, &ref_);
+        if (rc != CE_OK) throw Error(Error::Kind::MetricCalculation, "SSIM2 reference error: " + be_->last_error());
+    }
+    ~Ssimulacra2Reference() { ce_ref_destroy(ref_); }
+    Ssimulacra2Reference(const Ssimulacra2Reference &) = delete;
+    Ssimulacra2Reference &operator=(const Ssimulacra2Reference &) = delete;
+
+    double compare(const std::vector<uint8_t> &distorted) const
+    {
+        ce_scores s{};
+        const int rc = ce_ref_compare(ref_, distorted.data(), distorted.size(), CE_METRIC_SSIMULACRA2, CE_DEFAULT_INTENSITY_TARGET, &s);
+        detail::check(*be_, rc, "SSIMULACRA2", w_, h_, distorted.size());
+        return s.ssimulacra2;
+    }
+    // the sweep `for q in qualities { reference.compare(decoded[q]) }` (eval.rs:83-89) as one launch
+    std::vector<double> compare_many(const std::vector<std::vector<uint8_t>> &distorted) const
+    {
+        std::vector<const uint8_t *> ptrs;
+        std::vector<size_t> lens;
+        for (const auto &d : distorted) {
+            ptrs.push_back(d.data());
+            lens.push_back(d.size());
+        }
+        std::vector<ce_scores> s(distorted.size());
+        const int rc = ce_ref_compare_many(ref_, ptrs.data(), lens.data(), (uint32_t)distorted.size(), CE_METRIC_SSIMULACRA2,
+                                           CE_DEFAULT_INTENSITY_TARGET, s.data());
+        detail::check(*be_, rc, "SSIMULACRA2", w_, h_, 0);
+        std::vector<double> out;
+        for (size_t i = 0; i < s.size(); i++) {
+            detail::check(*be_, s[i].status, "SSIMULACRA2", w_, h_, lens[i]);
+            out.push_back(s[i].ssimulacra2);
+        }
+        return out;
+    }
+
+private:
+    std::shared_ptr<HipBackend> be_;
+    ce_ref *ref_ = nullptr;
+    size_t w_, h_;
+};
+
+// GpuSsim2 (crates/codec-iter/src/gpu.rs:21-134): `new(w, h)` fixes the shape, `compute(&mut self, ref, dis)`
+// takes packed RGB8 from host memory and returns the score; one call in flight per object.
+class GpuSsim2 {
+public:
+    GpuSsim2(uint32_t width, uint32_t height, int device = 0) : be_(std::make_shared<HipBackend>(device)), w_(width), h_(height) {}
+    double compute(const std::vector<uint8_t> &reference, const std::vector<uint8_t> &distorted)
+    {
+        const size_t expected = (size_t)w_ * h_ * 3;
+        if (reference.size() != expected || distorted.size() != expected)  // gpu.rs:84-94
+            throw std::runtime_error("Image size mismatch: expected " + std::to_string(expected) + " bytes (" + std::to_string(w_) + "x" +
+                                     std::to_string(h_) + "x3), got ref=" + std::to_string(reference.size()) +
+                                     " dis=" + std::to_string(distorted.size()));
+        double out = 0.0;
+        const int rc = ce_calculate_ssimulacra2(be_->ctx(), reference.data(), reference.size(), distorted.data(), distorted.size(), w_, h_, &out);
+        if (rc != CE_OK) throw std::runtime_error("SSIM2 HIP compute failed: " + be_->last_error());
+        return out;
+    }
+    std::pair<uint32_t, uint32_t> dimensions() const { return {w_, h_}; }
+    const std::shared_ptr<HipBackend> &backend() const { return be_; }
+
+private:
+    std::shared_ptr<HipBackend> be_;
+    uint32_t w_, h_;
+};
+
+// Ssim2Backend (eval.rs:56-92).  The reference's enum has a Gpu and a Cpu arm; this library IS the device arm,
+// so the mirror has that arm only (there is no CPU path in the product).  With a precomputed reference handle
+// the source image is not uploaded again.
+class Ssim2Backend {
+public:
+    explicit Ssim2Backend(std::unique_ptr<GpuSsim2> gpu) : gpu_(std::move(gpu)) {}
+    double compare_with_precomputed(const std::vector<uint8_t> &source, const std::vector<uint8_t> &decoded,
+                                    const Ssimulacra2Reference *reference, const std::string &image_name, unsigned quality)
+    {
+        try {
+            return reference ? reference->compare(decoded) : gpu_->compute(source, decoded);
+        } catch (const std::exception &e) {  // eval.rs:88
+            throw std::runtime_error("SSIM2 error for " + image_name + " q" + std::to_string(quality) + ": " + e.what());
+        }
+    }
+    GpuSsim2 &gpu() { return *gpu_; }
+
+private:
+    std::unique_ptr<GpuSsim2> gpu_;
+};
+
 // ---- src/eval/helpers.rs ---------------------------------------------------------------------------------
 // evaluate_single, helpers.rs:105-173 (RGB8 images)
 inline MetricResult evaluate_single(const HipBackend &be, const ImageData &reference, const ImageData &encoded, const MetricConfig &config)

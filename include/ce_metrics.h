@@ -161,11 +161,22 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out);
 int ce_batch_butteraugli_pnorm3(ce_batch *b, uint32_t n_pairs, double *out);
 
 /* ---- reference handle: Ssimulacra2Reference::{new,compare} ------------------------
- * crates/codec-iter/src/eval.rs:138-149,83-89; crates/codec-compare/src/brute_force_sweep.rs:197-201,256 */
+ * crates/codec-iter/src/eval.rs:138-149,83-89; crates/codec-compare/src/brute_force_sweep.rs:197-201,256
+ * The handle keeps the reference resident in HBM together with its reference-side state: the XYB
+ * roundtrip (CE_FLAG_XYB_ROUNDTRIP) and the SSIMULACRA2 XYB pyramid are built by the first compare and
+ * reused by every later one.  The blurred reference planes are NOT kept: the blur passes are bound by
+ * HBM traffic and a compare would read a cached plane just as it reads a recomputed one. */
 int ce_ref_create(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, uint32_t width, uint32_t height,
                   uint32_t flags, ce_ref **out);
 int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t metric_mask,
                    float intensity_target, ce_scores *out);
+/* The quality sweep of one reference in one launch: the loop
+ *   for q in qualities { reference.compare(decoded[q]) }      (eval.rs:83-89, brute_force_sweep.rs:256)
+ * as a single batch.  tests[i] / test_lens[i]: the i-th distorted image; out[i].status is per item
+ * (CE_ERR_DIM_MISMATCH for a wrong length, the others still run); the return value reports call-level
+ * failures only. */
+int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *test_lens, uint32_t n_tests,
+                        uint32_t metric_mask, float intensity_target, ce_scores *out);
 void ce_ref_destroy(ce_ref *ref);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------ */

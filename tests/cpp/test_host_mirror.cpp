@@ -166,6 +166,39 @@ static void with_gpu()
     for (size_t i = 3; i < 6; i++) {  // no decoder: size only (session.rs:411-428)
         CHECK(rep.results[i].codec_id == "size-only" && !rep.results[i].metrics.psnr && !rep.results[i].perception);
     }
+
+    // codec-iter's plug point (crates/codec-iter/src/eval.rs:56-149, gpu.rs:40-116): GpuSsim2::new(w, h) +
+    // compute(), Ssimulacra2Reference::new + compare() over the quality sweep, Ssim2Backend dispatch.
+    const auto a = src.to_rgb8_vec();
+    std::vector<std::vector<uint8_t>> decoded;
+    for (double q : {50.0, 75.0, 95.0}) {
+        current_step = 1 + (int)((100.0 - q) / 8.0);
+        decoded.push_back(decode(a).to_rgb8_vec());
+    }
+    eval::Ssim2Backend backend(std::make_unique<eval::GpuSsim2>(96, 80));
+    CHECK(backend.gpu().dimensions() == std::make_pair(96u, 80u));
+    const eval::Ssimulacra2Reference reference(be, a, 96, 80);
+    const std::vector<double> sweep = reference.compare_many(decoded);
+    for (size_t i = 0; i < decoded.size(); i++) {
+        const double direct = metrics::calculate_ssimulacra2(*be, a, decoded[i], 96, 80);
+        CHECK(backend.compare_with_precomputed(a, decoded[i], nullptr, "pattern.png", 50) == direct);     // uploads both
+        CHECK(backend.compare_with_precomputed(a, decoded[i], &reference, "pattern.png", 50) == direct);  // cached reference
+        CHECK(sweep[i] == direct);
+    }
+    bool size_err = false;
+    try {
+        backend.gpu().compute(a, std::vector<uint8_t>(10));
+    } catch (const std::runtime_error &e) {  // gpu.rs:84-94
+        size_err = std::string(e.what()).find("Image size mismatch: expected 23040 bytes (96x80x3), got ref=23040 dis=10") == 0;
+    }
+    CHECK(size_err);
+    bool named = false;
+    try {
+        backend.compare_with_precomputed(a, std::vector<uint8_t>(10), &reference, "pattern.png", 75);
+    } catch (const std::runtime_error &e) {  // eval.rs:88
+        named = std::string(e.what()).find("SSIM2 error for pattern.png q75: ") == 0;
+    }
+    CHECK(named);
 }
 
 int main(int argc, char **argv)

@@ -272,6 +272,59 @@ def test_reference_handle(gpu_ctx, oracle, ce, workloads):
     hd.close()
 
 
+def test_codec_iter_plug_point(gpu_ctx, oracle, ce, workloads):
+    # GpuSsim2::new/compute (gpu.rs:40-116) and Ssim2Backend::compare_with_precomputed (eval.rs:56-92)
+    w, h = 72, 56
+    ref = workloads.make_reference(w, h, 3)
+    t = workloads.distort(ref, 60)
+    gpu = ce.GpuSsim2(w, h)
+    assert gpu.dimensions() == (w, h)
+    want = oracle.ssimulacra2(ref, t, w, h, 1)
+    assert rel_close(gpu.compute(ref, t), want)
+    with pytest.raises(RuntimeError, match=r"Image size mismatch: expected 12096 bytes \(72x56x3\), got ref=12096 dis=10"):
+        gpu.compute(ref, t.reshape(-1)[:10])
+    backend = ce.Ssim2Backend(gpu)
+    hd = ce.Ssimulacra2Reference(gpu.ctx, ref, w, h)
+    assert backend.compare_with_precomputed(ref, t, None, "img", 60) == gpu.compute(ref, t)
+    assert backend.compare_with_precomputed(ref, t, hd, "img", 60) == gpu.compute(ref, t)
+    with pytest.raises(RuntimeError, match="SSIM2 error for img q60: "):
+        backend.compare_with_precomputed(ref, t.reshape(-1)[:10], hd, "img", 60)
+    hd.close()
+    gpu.close()
+
+
+def test_reference_handle_sweep_and_cached_reference_side(gpu_ctx, oracle, ce, workloads):
+    """The quality sweep of one reference in one launch (`for q { reference.compare(..) }`,
+    brute_force_sweep.rs:256), with the reference-side state (XYB roundtrip, XYB pyramid) built by the
+    first compare and reused afterwards: later compares must give exactly what a fresh evaluation gives."""
+    w, h = 96, 80
+    ref = workloads.make_reference(w, h, 21)
+    tests = [workloads.distort(ref, q) for q in (30, 55, 75, 90, 97)]
+    cfg = ce.MetricConfig.all()
+    for rt in (False, True):
+        hd = ce.ReferenceHandle(gpu_ctx, ref, w, h, xyb_roundtrip=rt)
+        first = hd.compare(tests[0], cfg)  # builds the reference side
+        many = hd.compare_many(tests, cfg)  # grows the handle to 5 slots, reuses nothing stale
+        again = hd.compare_many(tests[::-1], cfg)[::-1]  # reference side now cached
+        full = cfg.with_xyb_roundtrip() if rt else cfg
+        for t, m, a in zip(tests, many, again):
+            fresh = gpu_ctx.calculate_metrics(ref, t, w, h, full)
+            for name in ("psnr", "ssimulacra2", "dssim", "butteraugli"):
+                assert getattr(m, name) == getattr(fresh, name), (rt, name)
+                assert getattr(a, name) == getattr(fresh, name), (rt, name)
+        assert first.ssimulacra2 == many[0].ssimulacra2
+        # a wrong-sized item fails alone
+        res = hd.compare_many([tests[1], ref[:7], tests[2]], cfg)
+        assert isinstance(res[1], ce.DimensionMismatch)
+        assert res[0].ssimulacra2 == many[1].ssimulacra2 and res[2].ssimulacra2 == many[2].ssimulacra2
+        hd.close()
+    # against the oracle too (no roundtrip)
+    hd = ce.ReferenceHandle(gpu_ctx, ref, w, h)
+    for t, m in zip(tests, hd.compare_many(tests)):
+        assert rel_close(m.ssimulacra2, oracle.ssimulacra2(ref, t, w, h, 1))
+    hd.close()
+
+
 # ------------------------------------------------------------------------ DSSIM ----------------
 
 
