@@ -3,6 +3,8 @@
 // kinds, profiling hooks.  All device work is in the .hip files; there is no CPU compute
 // path here — if HIP is unavailable every entry point fails with CE_ERR_BACKEND.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -207,7 +209,13 @@ int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_r
     chk(hipMalloc(&b->d_pair_ref, sizeof(uint32_t) * max_pairs), "hipMalloc pair_ref");
     chk(hipMalloc(&b->d_scores, sizeof(ce_dev_scores) * max_pairs), "hipMalloc scores");
     chk(hipHostMalloc(&b->h_scores, sizeof(ce_dev_scores) * max_pairs, hipHostMallocDefault), "hipHostMalloc scores");
-    chk(hipHostMalloc(&b->h_stage, b->img_bytes, hipHostMallocDefault), "hipHostMalloc stage");
+    chk(hipStreamCreateWithFlags(&b->up_stream, hipStreamNonBlocking), "hipStreamCreate upload");
+    chk(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming), "hipEventCreate");
+    chk(hipEventCreateWithFlags(&b->ev_run, hipEventDisableTiming), "hipEventCreate");
+    for (int k = 0; k < ce_batch::kStages; k++) {
+        chk(hipHostMalloc(&b->h_stage[k], b->img_bytes, hipHostMallocDefault), "hipHostMalloc stage");
+        chk(hipEventCreateWithFlags(&b->ev_stage[k], hipEventDisableTiming), "hipEventCreate stage");
+    }
     if (rc == CE_OK) chk(hipMemsetAsync(b->d_scores, 0, sizeof(ce_dev_scores) * max_pairs, ctx->stream), "memset");
     if (rc != CE_OK) {
         ce_batch_destroy(b);
@@ -222,13 +230,19 @@ void ce_batch_destroy(ce_batch *b)
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
+    if (b->up_stream) hipStreamSynchronize(b->up_stream), hipStreamDestroy(b->up_stream);
+    if (b->ev_up) hipEventDestroy(b->ev_up);
+    if (b->ev_run) hipEventDestroy(b->ev_run);
     hipFree(b->d_refs);
     hipFree(b->d_refs_rt);
     hipFree(b->d_tests);
     hipFree(b->d_pair_ref);
     hipFree(b->d_scores);
     if (b->h_scores) hipHostFree(b->h_scores);
-    if (b->h_stage) hipHostFree(b->h_stage);
+    for (int k = 0; k < ce_batch::kStages; k++) {
+        if (b->h_stage[k]) hipHostFree(b->h_stage[k]);
+        if (b->ev_stage[k]) hipEventDestroy(b->ev_stage[k]);
+    }
     for (auto &p : b->d_lin) hipFree(p);
     for (int l = 0; l < CE_MAX_SCALES; l++) {
         hipFree(b->d_xyb[l]);
@@ -247,11 +261,93 @@ void ce_batch_destroy(ce_batch *b)
 static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src)
 {
     ce_ctx *ctx = b->ctx;
-    // pageable source -> pinned staging -> device, ordered on the context's stream
-    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(b->h_stage, src, b->img_bytes);
-    CE_HIP(ctx, hipMemcpyAsync(dst, b->h_stage, b->img_bytes, hipMemcpyHostToDevice, ctx->stream));
-    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // pageable source -> pinned staging ring -> device on the batch's upload stream.  The caller's buffer is
+    // consumed before this returns; the DMA of this slot overlaps the host copy into the next one and the
+    // kernels of other batches.  A launched-but-uncollected run of THIS batch still reads the slabs: wait for it.
+    if (b->run_pending) {
+        CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
+        b->run_pending = false;  // ordered from here on
+    }
+    const int k = b->next_stage;
+    b->next_stage = (k + 1) % ce_batch::kStages;
+    if (b->stage_busy[k]) CE_HIP(ctx, hipEventSynchronize(b->ev_stage[k]));
+    std::memcpy(b->h_stage[k], src, b->img_bytes);
+    CE_HIP(ctx, hipMemcpyAsync(dst, b->h_stage[k], b->img_bytes, hipMemcpyHostToDevice, b->up_stream));
+    CE_HIP(ctx, hipEventRecord(b->ev_stage[k], b->up_stream));
+    b->stage_busy[k] = true;
+    b->uploads_pending = true;
+    return CE_OK;
+}
+
+// kernels (context stream) must see everything uploaded so far
+static int flush_uploads(ce_batch *b)
+{
+    if (!b->uploads_pending) return CE_OK;
+    ce_ctx *ctx = b->ctx;
+    CE_HIP(ctx, hipEventRecord(b->ev_up, b->up_stream));
+    CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_up, 0));
+    b->uploads_pending = false;
+    return CE_OK;
+}
+
+// Many images at once (ce_eval_batch): the host copies into the pinned ring are spread over a few threads, each
+// with its own pair of ring slots, because one thread's memcpy (~12 GB/s) is slower than the PCIe link.
+struct upload_job {
+    uint8_t *dst;
+    const uint8_t *src;
+};
+
+static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
+{
+    ce_ctx *ctx = b->ctx;
+    if (jobs.empty()) return CE_OK;
+    const int n_threads = (int)std::min<size_t>({(size_t)ce_batch::kStages / 2, jobs.size(),
+                                                 (size_t)std::max(1u, std::thread::hardware_concurrency())});
+    if (n_threads <= 1 || b->img_bytes < (64u << 10)) {
+        for (const auto &j : jobs) {
+            int rc = upload(b, j.dst, j.src);
+            if (rc != CE_OK) return rc;
+        }
+        return CE_OK;
+    }
+    if (b->run_pending) {
+        CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
+        b->run_pending = false;
+    }
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{(int)hipSuccess};
+    const int device = ctx->device;
+    auto worker = [&](int t) {
+        if (hipSetDevice(device) != hipSuccess) return;
+        int flip = 0;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= jobs.size()) break;
+            const int k = 2 * t + flip;
+            flip ^= 1;
+            hipError_t e = hipSuccess;
+            if (b->stage_busy[k]) e = hipEventSynchronize(b->ev_stage[k]);
+            if (e == hipSuccess) {
+                std::memcpy(b->h_stage[k], jobs[i].src, b->img_bytes);
+                e = hipMemcpyAsync(jobs[i].dst, b->h_stage[k], b->img_bytes, hipMemcpyHostToDevice, b->up_stream);
+            }
+            if (e == hipSuccess) e = hipEventRecord(b->ev_stage[k], b->up_stream);
+            b->stage_busy[k] = true;
+            if (e != hipSuccess) {
+                err.store((int)e);
+                break;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &th : pool) th.join();
+    b->uploads_pending = true;
+    if (err.load() != (int)hipSuccess) {
+        ctx->err = std::string("upload: ") + hipGetErrorString((hipError_t)err.load());
+        return CE_ERR_BACKEND;
+    }
     return CE_OK;
 }
 
@@ -307,6 +403,10 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     const uint32_t known = CE_METRIC_DSSIM | CE_METRIC_SSIMULACRA2 | CE_METRIC_BUTTERAUGLI | CE_METRIC_PSNR;
     if (metric_mask & ~known) return fail(ctx, CE_ERR_INVALID_ARG, "unknown metric bit");
     CE_HIP(ctx, hipSetDevice(ctx->device));
+    {
+        int rc = flush_uploads(b);
+        if (rc != CE_OK) return rc;
+    }
     if (b->pair_ref_dirty) {
         CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, b->h_pair_ref.data(), sizeof(uint32_t) * b->max_pairs,
                                    hipMemcpyHostToDevice, ctx->stream));
@@ -345,6 +445,8 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     }
     b->last_n_pairs = n_pairs;
     b->last_mask = metric_mask;
+    CE_HIP(ctx, hipEventRecord(b->ev_run, ctx->stream));
+    b->run_pending = true;
     return CE_OK;
 }
 
@@ -356,6 +458,7 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
     CE_HIP(ctx, hipMemcpyAsync(b->h_scores, b->d_scores, sizeof(ce_dev_scores) * n_pairs, hipMemcpyDeviceToHost,
                                ctx->stream));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    b->run_pending = false;
     const uint32_t mask = b->last_mask;
     for (uint32_t i = 0; i < n_pairs; i++) {
         ce_scores s{};
@@ -447,6 +550,9 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
         }
         buckets[{d.width, d.height}].push_back(i);
     }
+    // Phase 1: fill and launch every shape bucket (uploads of one bucket overlap the kernels of the previous one);
+    // phase 2: collect.
+    std::vector<ce_batch *> launched;
     for (auto &kv : buckets) {
         const std::vector<size_t> &idx = kv.second;
         ce_batch *b = nullptr;
@@ -454,23 +560,35 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
         if (rc != CE_OK) return rc;
         // identical reference pointers share one device slot (the quality sweep of one source image)
         std::map<const uint8_t *, uint32_t> ref_slot;
+        std::vector<upload_job> jobs;
         for (size_t k = 0; k < idx.size(); k++) {
-            const ce_pair_desc &d = pairs[idx[k]];
+            const ce_pair_desc &d = pairs[idx[k]];  // lengths were validated above against this bucket's shape
             auto it = ref_slot.find(d.reference);
             uint32_t slot;
             if (it == ref_slot.end()) {
                 slot = (uint32_t)ref_slot.size();
                 ref_slot[d.reference] = slot;
-                rc = ce_batch_set_reference(b, slot, d.reference, d.reference_len);
-                if (rc != CE_OK) return rc;
+                jobs.push_back({b->d_refs + (size_t)slot * b->img_bytes, d.reference});
             } else {
                 slot = it->second;
             }
-            rc = ce_batch_set_test(b, (uint32_t)k, slot, d.test, d.test_len);
+            rc = ce_batch_bind_pair(b, (uint32_t)k, slot);
             if (rc != CE_OK) return rc;
+            jobs.push_back({b->d_tests + (size_t)k * b->img_bytes, d.test});
         }
+        b->ssim2_ref_src = nullptr;
+        b->refs_rt_valid = false;
+        rc = upload_many(b, jobs);
+        if (rc != CE_OK) return rc;
+        rc = ce_batch_launch(b, (uint32_t)idx.size(), metric_mask, flags, intensity_target);
+        if (rc != CE_OK) return rc;
+        launched.push_back(b);
+    }
+    size_t bi = 0;
+    for (auto &kv : buckets) {
+        const std::vector<size_t> &idx = kv.second;
         std::vector<ce_scores> tmp(idx.size());
-        rc = ce_batch_run(b, (uint32_t)idx.size(), metric_mask, flags, intensity_target, tmp.data());
+        int rc = ce_batch_collect(launched[bi++], (uint32_t)idx.size(), tmp.data());
         if (rc != CE_OK) return rc;
         for (size_t k = 0; k < idx.size(); k++) out[idx[k]] = tmp[k];
     }
@@ -619,6 +737,8 @@ int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *
         // grow the handle: a new batch of the same shape takes over the resident reference (device copy)
         ce_batch *nb = nullptr;
         int rc = ce_batch_create(ctx, b->w, b->h, 1, n_tests, &nb);
+        if (rc != CE_OK) return rc;
+        rc = flush_uploads(b);
         if (rc != CE_OK) return rc;
         CE_HIP(ctx, hipMemcpyAsync(nb->d_refs, b->d_refs, b->img_bytes, hipMemcpyDeviceToDevice, ctx->stream));
         CE_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -74,7 +74,16 @@ struct ce_batch {
     uint32_t *d_pair_ref = nullptr;
     std::vector<uint32_t> h_pair_ref;
     bool pair_ref_dirty = true;
-    uint8_t *h_stage = nullptr;  // pinned staging, one image
+    // pinned staging ring for host -> device uploads: the host copy into slot k overlaps the DMA of slot k-1
+    static constexpr int kStages = 8;  // two per upload worker (ce_eval_batch fills a bucket with 4 host threads)
+    uint8_t *h_stage[kStages] = {};
+    hipEvent_t ev_stage[kStages] = {};
+    bool stage_busy[kStages] = {};
+    int next_stage = 0;
+    // uploads run on their own stream so that filling one batch overlaps another batch's kernels
+    hipStream_t up_stream = nullptr;
+    hipEvent_t ev_up = nullptr, ev_run = nullptr;  // uploads done / last launch done
+    bool uploads_pending = false, run_pending = false;
 
     // SSIMULACRA2 working set.  Image slots: [0, max_refs) references, then tests.
     int n_scales = 0;
