@@ -26,6 +26,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 CE_OK, CE_ERR_DIM_MISMATCH, CE_ERR_BAD_LENGTH, CE_ERR_TOO_SMALL, CE_ERR_BACKEND, CE_ERR_INVALID_ARG = range(6)
 METRIC_DSSIM, METRIC_SSIMULACRA2, METRIC_BUTTERAUGLI, METRIC_PSNR = 1, 2, 4, 8
 FLAG_XYB_ROUNDTRIP = 1
+PIXEL_RGB8, PIXEL_RGBA8, PIXEL_RGB16_10BIT, PIXEL_RGBA16_10BIT = 0, 1, 2, 3
 DEFAULT_INTENSITY_TARGET = 80.0
 
 _STATUS_NAMES = {
@@ -117,6 +118,8 @@ _PROTOTYPES = [
     ("ce_batch_destroy", None, [_vp]),
     ("ce_batch_set_reference", _i, [_vp, _u32, _u8p, _sz]),
     ("ce_batch_set_test", _i, [_vp, _u32, _u32, _u8p, _sz]),
+    ("ce_batch_set_reference_fmt", _i, [_vp, _u32, _vp, _sz, _i]),
+    ("ce_batch_set_test_fmt", _i, [_vp, _u32, _u32, _vp, _sz, _i]),
     ("ce_batch_reference_slab", _vp, [_vp]),
     ("ce_batch_test_slab", _vp, [_vp]),
     ("ce_batch_bind_pair", _i, [_vp, _u32, _u32]),
@@ -435,6 +438,15 @@ class Batch:
     def set_test(self, pair_index: int, ref_index: int, rgb):
         t = _buf(rgb)
         self.ctx._check(lib().ce_batch_set_test(self._h, pair_index, ref_index, t.ctypes.data, t.size))
+
+    # decoded-image ingest: pixels as a decoder hands them over, converted to RGB8 on the device
+    def set_reference_fmt(self, ref_index: int, pixels, fmt: int):
+        a = np.ascontiguousarray(pixels)
+        self.ctx._check(lib().ce_batch_set_reference_fmt(self._h, ref_index, a.ctypes.data, a.nbytes, fmt))
+
+    def set_test_fmt(self, pair_index: int, ref_index: int, pixels, fmt: int):
+        a = np.ascontiguousarray(pixels)
+        self.ctx._check(lib().ce_batch_set_test_fmt(self._h, pair_index, ref_index, a.ctypes.data, a.nbytes, fmt))
 
     def bind_pair(self, pair_index: int, ref_index: int):
         self.ctx._check(lib().ce_batch_bind_pair(self._h, pair_index, ref_index))

@@ -231,6 +231,8 @@ void ce_batch_destroy(ce_batch *b)
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     if (b->up_stream) hipStreamSynchronize(b->up_stream), hipStreamDestroy(b->up_stream);
+    if (b->h_wide) hipHostFree(b->h_wide);
+    hipFree(b->d_wide);
     if (b->ev_up) hipEventDestroy(b->ev_up);
     if (b->ev_run) hipEventDestroy(b->ev_run);
     hipFree(b->d_refs);
@@ -363,6 +365,42 @@ int ce_batch_set_reference(ce_batch *b, uint32_t ref_index, const uint8_t *rgb, 
     return upload(b, b->d_refs + (size_t)ref_index * b->img_bytes, rgb);
 }
 
+// pixels in a decoder's format -> wide staging -> device -> ingest kernel writes the RGB8 slab slot
+static int upload_fmt(ce_batch *b, uint8_t *dst, const void *pixels, size_t len, int format)
+{
+    ce_ctx *ctx = b->ctx;
+    const size_t bpp = ce_pixel_bytes(format), n_px = (size_t)b->w * b->h;
+    if (bpp == 0) return fail(ctx, CE_ERR_INVALID_ARG, "unknown pixel format");
+    if (len != n_px * bpp)
+        return fail(ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(n_px * bpp) + " bytes, got " +
+                                                std::to_string(len));
+    if (format == CE_PIXEL_RGB8) return upload(b, dst, static_cast<const uint8_t *>(pixels));
+    if (!b->h_wide) {
+        CE_HIP(ctx, hipHostMalloc(&b->h_wide, n_px * 8, hipHostMallocDefault));
+        CE_HIP(ctx, hipMalloc(&b->d_wide, n_px * 8));
+    }
+    if (b->run_pending) {
+        CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
+        b->run_pending = false;
+    }
+    CE_HIP(ctx, hipStreamSynchronize(b->up_stream));  // the single wide staging image is free again
+    std::memcpy(b->h_wide, pixels, len);
+    CE_HIP(ctx, hipMemcpyAsync(b->d_wide, b->h_wide, len, hipMemcpyHostToDevice, b->up_stream));
+    int rc = ce_launch_ingest(ctx, b->up_stream, format, b->d_wide, dst, n_px);
+    if (rc != CE_OK) return rc;
+    b->uploads_pending = true;
+    return CE_OK;
+}
+
+int ce_batch_set_reference_fmt(ce_batch *b, uint32_t ref_index, const void *pixels, size_t len, int format)
+{
+    if (!b || !pixels) return CE_ERR_INVALID_ARG;
+    if (ref_index >= b->max_refs) return fail(b->ctx, CE_ERR_INVALID_ARG, "ref_index out of range");
+    b->ssim2_ref_src = nullptr;
+    b->refs_rt_valid = false;
+    return upload_fmt(b, b->d_refs + (size_t)ref_index * b->img_bytes, pixels, len, format);
+}
+
 int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index)
 {
     if (!b) return CE_ERR_INVALID_ARG;
@@ -384,6 +422,14 @@ int ce_batch_set_test(ce_batch *b, uint32_t pair_index, uint32_t ref_index, cons
         return fail(b->ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(b->img_bytes) +
                                                     " bytes, got " + std::to_string(len));
     return upload(b, b->d_tests + (size_t)pair_index * b->img_bytes, rgb);
+}
+
+int ce_batch_set_test_fmt(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const void *pixels, size_t len, int format)
+{
+    if (!b || !pixels) return CE_ERR_INVALID_ARG;
+    int rc = ce_batch_bind_pair(b, pair_index, ref_index);
+    if (rc != CE_OK) return rc;
+    return upload_fmt(b, b->d_tests + (size_t)pair_index * b->img_bytes, pixels, len, format);
 }
 
 void *ce_batch_reference_slab(ce_batch *b)

@@ -84,6 +84,8 @@ struct ce_batch {
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up = nullptr, ev_run = nullptr;  // uploads done / last launch done
     bool uploads_pending = false, run_pending = false;
+    // wide ingest (RGBA8 / 16-bit sources): one pinned + one device staging image of 8 B/px, made on first use
+    uint8_t *h_wide = nullptr, *d_wide = nullptr;
 
     // SSIMULACRA2 working set.  Image slots: [0, max_refs) references, then tests.
     int n_scales = 0;
@@ -169,6 +171,8 @@ void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream);
 
 // ---- kernel launchers (one .hip file per metric) ---------------------------------------
 int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);
+size_t ce_pixel_bytes(int format);
+int ce_launch_ingest(ce_ctx *ctx, hipStream_t stream, int format, const void *d_src, uint8_t *d_dst, size_t n_pixels);
 int ce_ssim2_prepare(ce_batch *b);
 int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);
 int ce_ssim2_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path);

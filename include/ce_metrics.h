@@ -142,6 +142,20 @@ void ce_batch_destroy(ce_batch *b);
 /* host -> device copies (pinned staging inside) */
 int ce_batch_set_reference(ce_batch *b, uint32_t ref_index, const uint8_t *rgb, size_t len);
 int ce_batch_set_test(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const uint8_t *rgb, size_t len);
+/* Decoded-image ingest: the same two calls for pixels as a decoder hands them over.  The conversion to the
+ * packed RGB8 the metrics read happens on the device (no per-pixel pass on the host):
+ *   CE_PIXEL_RGBA8         alpha dropped          ImageData::to_rgb8_vec, src/eval/session.rs:98-117
+ *   CE_PIXEL_RGB16_10BIT   ((v*255+512)/1023).min(255) per sample, u16 little endian
+ *   CE_PIXEL_RGBA16_10BIT  both                   to_8bit / pixel_data_to_rgb8, crates/codec-iter/src/avif_config.rs:122-170
+ * len is in bytes and must be width * height * bytes-per-pixel of the format. */
+enum {
+    CE_PIXEL_RGB8 = 0,
+    CE_PIXEL_RGBA8 = 1,
+    CE_PIXEL_RGB16_10BIT = 2,
+    CE_PIXEL_RGBA16_10BIT = 3
+};
+int ce_batch_set_reference_fmt(ce_batch *b, uint32_t ref_index, const void *pixels, size_t len, int format);
+int ce_batch_set_test_fmt(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const void *pixels, size_t len, int format);
 /* device pointers of the packed u8 slabs ([max_refs][h][w][3], [max_pairs][h][w][3]) so a caller that
  * already has pixels in HBM (e.g. a GPU decoder) can write them in place */
 void *ce_batch_reference_slab(ce_batch *b);

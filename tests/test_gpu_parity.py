@@ -272,6 +272,41 @@ def test_reference_handle(gpu_ctx, oracle, ce, workloads):
     hd.close()
 
 
+def test_decoded_image_ingest_on_device(gpu_ctx, ce, workloads):
+    """RGBA8 / 10-bit RGB16 / RGBA16 decoder outputs are converted to the RGB8 slab on the device; the result must be
+    the bytes the reference's host passes produce (session.rs:98-117 alpha strip; avif_config.rs:122-125 to_8bit),
+    restated here in numpy.  PSNR against the numpy-converted image is +inf exactly when every byte agrees."""
+    w, h = 97, 61  # odd sizes: no alignment to lean on
+    rng = np.random.default_rng(5)
+    ref = workloads.make_reference(w, h, 11)
+    rgb = workloads.distort(ref, 70).reshape(h, w, 3)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+    v10 = rng.integers(0, 1024, (h, w, 3), dtype=np.uint16)
+    v10[0, :8] = [[0, 1, 2], [3, 4, 510], [511, 512, 513], [1021, 1022, 1023], [1024, 2047, 65535], [2, 2, 2], [1000, 100, 10], [7, 77, 777]]
+    rgb16_as8 = np.minimum((v10.astype(np.uint32) * 255 + 512) // 1023, 255).astype(np.uint8)
+    rgba16 = np.concatenate([v10, rng.integers(0, 1024, (h, w, 1), dtype=np.uint16)], axis=2)
+    cfg = ce.MetricConfig.all()
+    cases = [(rgba, ce.PIXEL_RGBA8, rgb), (v10, ce.PIXEL_RGB16_10BIT, rgb16_as8), (rgba16, ce.PIXEL_RGBA16_10BIT, rgb16_as8),
+             (rgb, ce.PIXEL_RGB8, rgb)]
+    b = ce.Batch(gpu_ctx, w, h, 2, 2)
+    for pixels, fmt, want in cases:
+        # slot 0: reference = device-ingested image, test = numpy-converted image -> must be identical
+        b.set_reference_fmt(0, pixels, fmt)
+        b.set_test(0, 0, want)
+        # slot 1: same test image both ways against a real reference -> same scores
+        b.set_reference(1, ref)
+        b.set_test_fmt(1, 1, pixels, fmt)
+        s = b.run(2, cfg)
+        assert s[0].psnr == float("inf") and s[0].dssim == 0.0 and s[0].ssimulacra2 == 100.0
+        direct = gpu_ctx.calculate_metrics(ref, want, w, h, cfg)
+        assert (s[1].psnr, s[1].ssimulacra2, s[1].dssim, s[1].butteraugli) == (direct.psnr, direct.ssimulacra2, direct.dssim, direct.butteraugli)
+    with pytest.raises(ce.MetricCalculation):
+        b.set_test_fmt(0, 0, rgba[:-1], ce.PIXEL_RGBA8)  # wrong length
+    with pytest.raises(ce.CodecEvalError):
+        b.set_test_fmt(0, 0, rgba, 9)  # unknown format
+    b.close()
+
+
 def test_codec_iter_plug_point(gpu_ctx, oracle, ce, workloads):
     # GpuSsim2::new/compute (gpu.rs:40-116) and Ssim2Backend::compare_with_precomputed (eval.rs:56-92)
     w, h = 72, 56
