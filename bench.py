@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--refs", type=int, default=0, help="override the number of reference images (configs 3-5)")
     ap.add_argument("--no-events", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
     ap.add_argument("--one-context", action="store_true", help="all shape buckets on one context (buckets run back to back)")
+    ap.add_argument("--all-events", action="store_true", help="events around every kernel in the timed region, not only level 0")
     ap.add_argument("--solo", action="store_true", help="extra pass: time every kernel alone on one stream")
     ap.add_argument("--depth", type=int, default=1,
                     help="batches in flight per shape bucket (1 = launch and collect each step before the next)")
@@ -159,6 +160,9 @@ def main():
     events = not args.no_events
     all_ctxs = list({id(c): c for cs, _ in sets for c in cs}.values())
     for c in all_ctxs:
+        # --all-events: every kernel; default: only the level-0 kernels (the candidates for the dominant kernel),
+        # which keeps the cost of the events in the timed region near 1 %
+        c.prof_filter("" if args.all_events else "_L0")
         c.prof_enable(events, serial=False)
 
     run_steps(args.warmup)
@@ -200,6 +204,7 @@ def main():
         # optional extra pass: one kernel at a time on one stream ("solo" durations, no sharing of the GPU)
         for c in ctxs:
             c.prof_reset()
+            c.prof_filter("")
             c.prof_enable(True, serial=True)
         for _ in range(args.steps):
             for g, b in batches:
@@ -212,11 +217,32 @@ def main():
             c.prof_enable(False)
     if rank == 0 and kernels:
         total_ms = sum(ms for _, ms in kernels.values())
-        name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
         px0 = sum(len(g.pairs) * g.width * g.height for g in grids)  # scale-0 pixels per step
+
+        def tail_pixels(w, h):  # pyramid levels 1..5 (ceil halving; a level exists while both sides are >= 8)
+            n, lv = 0, 1
+            while lv < 6:
+                w, h = (w + 1) // 2, (h + 1) // 2
+                if min(w, h) < 8:
+                    break
+                n += w * h
+                lv += 1
+            return n
+
+        px_tail = sum(len(g.pairs) * tail_pixels(g.width, g.height) for g in grids)
+        # SURVEY.md §8(d) algorithmic bytes per step of each kernel (R1-R6): a blur pass moves 60 B of blurred planes per
+        # pixel plus its inputs (6 B of u8 at level 0, 24 B of f32 above); the front end reads/writes 6+6 and 24+6
+        alg_bytes = {
+            "ssim2_hblur_L0": SSIM2_PASS_BYTES_L0 * px0, "ssim2_vblur_ssim_L0": SSIM2_PASS_BYTES_L0 * px0,
+            "ssim2_hblur_L1-5": 84.0 * px_tail, "ssim2_vblur_ssim_L1-5": 84.0 * px_tail,
+            "ssim2_prep_u8": 12.0 * px0, "ssim2_prep": 30.0 * px_tail,
+        }
+        # dominant kernel = the one that moves the largest share of the step's algorithmic bytes (ties: the slower)
+        name, (launches, ms) = max(((k, v) for k, v in kernels.items() if k in alg_bytes),
+                                   key=lambda kv: (alg_bytes[kv[0]], kv[1][1]), default=max(kernels.items(), key=lambda kv: kv[1][1]))
         n_launch_per_step = launches / args.steps
         avg_s = ms / launches * 1e-3
-        bytes_per_launch = SSIM2_PASS_BYTES_L0 * px0 / n_launch_per_step
+        bytes_per_launch = alg_bytes.get(name, 0.0) / n_launch_per_step
         achieved = bytes_per_launch / avg_s / 1e9
         traffic = None  # HBM bytes per launch from the PMC counters (profiles/traffic_r01.json, separate --pmc passes)
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -238,7 +264,7 @@ def main():
             "launches": launches,
             "timing": "HIP events on the launch stream, in the timed region; kernels of other pyramid levels and of "
                       "the other shape bucket run concurrently on other streams",
-            "kernel_share_of_gpu_time": round(ms / total_ms, 3),
+            "dominant_by": "largest share of the step's algorithmic bytes (%.0f %%)" % (100.0 * alg_bytes.get(name, 0.0) / (SSIM2_BYTES_PER_PX0_TOTAL * px0)),
             # the whole metric against the same peak: 210 B per scale-0 pixel over the timed step
             "pipeline_achieved": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9, 1),
             "pipeline_frac": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

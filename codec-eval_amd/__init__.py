@@ -132,6 +132,7 @@ _PROTOTYPES = [
     ("ce_ref_compare_many", _i, [_vp, C.POINTER(_u8p), C.POINTER(_sz), _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_ref_destroy", None, [_vp]),
     ("ce_prof_enable", _i, [_vp, _i]),
+    ("ce_prof_filter", _i, [_vp, C.c_char_p]),
     ("ce_prof_reset", _i, [_vp]),
     ("ce_prof_count", _i, [_vp]),
     ("ce_prof_get", _i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), _dp]),
@@ -389,6 +390,10 @@ class Context:
         """Per-kernel HIP-event timing.  serial=True: one kernel at a time on the context's stream (solo
         times); serial=False: keep the batch's multi-stream schedule (times as rocprofv3 sees them)."""
         self._check(lib().ce_prof_enable(self._h, 0 if not on else (1 if serial else 2)))
+
+    def prof_filter(self, substring: str = ""):
+        """Only kernels whose name contains `substring` get events ("" = all)."""
+        self._check(lib().ce_prof_filter(self._h, substring.encode()))
 
     def prof_reset(self):
         self._check(lib().ce_prof_reset(self._h))

@@ -49,6 +49,7 @@ double psnr_from_sse(unsigned long long sse, size_t w, size_t h)
 
 int ce_prof_begin(ce_ctx *ctx, const char *name, hipStream_t stream)
 {
+    if (!ctx->prof_filter.empty() && !std::strstr(name, ctx->prof_filter.c_str())) return -1;
     int idx = -1;
     for (size_t i = 0; i < ctx->stats.size(); i++)
         if (ctx->stats[i].name == name) { idx = (int)i; break; }
@@ -846,6 +847,14 @@ int ce_prof_enable(ce_ctx *ctx, int on)
     prof_drain(ctx);
     ctx->prof = on != 0;
     ctx->prof_serial = on == 1;
+    return CE_OK;
+}
+
+int ce_prof_filter(ce_ctx *ctx, const char *substring)
+{
+    if (!ctx) return CE_ERR_INVALID_ARG;
+    prof_drain(ctx);
+    ctx->prof_filter = substring ? substring : "";
     return CE_OK;
 }
 

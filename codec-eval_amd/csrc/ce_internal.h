@@ -53,6 +53,7 @@ struct ce_ctx {
     // profiling
     bool prof = false;         // record a HIP event pair around every launch (on the launch's own stream)
     bool prof_serial = false;  // ...and keep everything on the context's stream so kernel times do not overlap
+    std::string prof_filter;   // non-empty: only kernels whose name contains this get events
     std::vector<ce_kernel_stat> stats;
     struct pending { int stat; hipEvent_t e0, e1; };
     std::vector<pending> pend;

@@ -28,6 +28,19 @@ struct rg_consts {
 
 constexpr int kColsPerBlock = 64;
 
+// Pyramid levels 1.. share ONE row-pass launch and ONE column-pass launch (kernel instance LEVEL = -1): the
+// launch's blockIdx.x runs over the levels' blocks back to back and this table maps a block to its level.
+// Five tiny, latency-bound launches per pass become one that fills the machine.
+constexpr int kTailLevels = CE_MAX_SCALES - 1;
+struct lvl_table {
+    uint32_t n, first_level;
+    uint32_t blk_end[kTailLevels];  // exclusive prefix ends of the levels' blockIdx.x ranges
+    uint32_t w[kTailLevels], h[kTailLevels], pitch[kTailLevels];
+    size_t plane[kTailLevels];
+    const float *xyb[kTailLevels];
+    float *hbuf[kTailLevels];
+};
+
 __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, uint32_t max_refs)
 {
     return z < n_refs_used ? z : max_refs + (z - n_refs_used);
@@ -271,13 +284,21 @@ __global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *
                                                                    const uint32_t *__restrict__ pair_ref,
                                                                    float *__restrict__ hbuf, uint32_t w, uint32_t h,
                                                                    uint32_t pitch, size_t plane, uint32_t max_refs,
-                                                                   rg_consts rg)
+                                                                   rg_consts rg, lvl_table tab)
 {
     __shared__ float s_in[2][2 * HB_HALF];  // [plane a|b][half][column][row]
     __shared__ float s_out[CE_SSIM2_STREAMS * HB_HALF];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t s = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform stream index
-    const uint32_t y0 = blockIdx.x * HB_ROWS, c = blockIdx.y, p = blockIdx.z;
+    uint32_t bx = blockIdx.x;
+    if (LEVEL < 0) {  // merged launch: which level does this block belong to?
+        uint32_t l = 0;
+        while (l + 1 < tab.n && bx >= tab.blk_end[l]) l++;
+        bx -= l ? tab.blk_end[l - 1] : 0;
+        xyb = tab.xyb[l], hbuf = tab.hbuf[l];
+        w = tab.w[l], h = tab.h[l], pitch = tab.pitch[l], plane = tab.plane[l];
+    }
+    const uint32_t y0 = bx * HB_ROWS, c = blockIdx.y, p = blockIdx.z;
     const float *ga = xyb + ((size_t)pair_ref[p] * 3 + c) * plane;
     const float *gb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane;
     const int n_chunks = (int)(pitch / HB_CW);  // N + 1
@@ -436,10 +457,19 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
                                                         const uint32_t *__restrict__ pair_ref,
                                                         double *__restrict__ partials, uint32_t w, uint32_t h,
                                                         uint32_t pitch, size_t plane, uint32_t max_refs, uint32_t scale,
-                                                        uint32_t max_vblocks, rg_consts rg)
+                                                        uint32_t max_vblocks, rg_consts rg, lvl_table tab)
 {
     __shared__ __attribute__((aligned(16))) float ring[2 * VB_GROUP];
-    const uint32_t lane = threadIdx.x, x0 = blockIdx.x * 64;
+    uint32_t bx = blockIdx.x;
+    if (LEVEL < 0) {  // merged launch: which level does this block belong to?
+        uint32_t l = 0;
+        while (l + 1 < tab.n && bx >= tab.blk_end[l]) l++;
+        bx -= l ? tab.blk_end[l - 1] : 0;
+        xyb = tab.xyb[l], hbuf = tab.hbuf[l];
+        w = tab.w[l], h = tab.h[l], pitch = tab.pitch[l], plane = tab.plane[l];
+        scale = tab.first_level + l;
+    }
+    const uint32_t lane = threadIdx.x, x0 = bx * 64;
     const uint32_t c = blockIdx.y, p = blockIdx.z;
     const bool active = x0 + lane < w;
     const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + x0;
@@ -513,7 +543,7 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
     }
 #undef CE_VGROUP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may land after the wave has retired
-    double *dst = partials + ((((size_t)p * CE_MAX_SCALES + scale) * 3 + c) * max_vblocks + blockIdx.x) * 6;
+    double *dst = partials + ((((size_t)p * CE_MAX_SCALES + scale) * 3 + c) * max_vblocks + bx) * 6;
 #pragma unroll
     for (int q = 0; q < 6; q++) {
         const double sum = wave_sum(active ? st.acc[q] : 0.0);
@@ -654,23 +684,22 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     const bool cached = b->keep_ref_pyramid && b->ssim2_ref_src == d_refs && b->ssim2_ref_count >= n_refs_used &&
                         b->ssim2_ref_levels == std::min(b->n_scales, b->debug_max_scales);
     const uint32_t z0 = cached ? n_refs_used : 0;
-    static const char *const kHName[CE_MAX_SCALES] = {"ssim2_hblur_L0", "ssim2_hblur_L1", "ssim2_hblur_L2",
-                                                      "ssim2_hblur_L3", "ssim2_hblur_L4", "ssim2_hblur_L5"};
-    static const char *const kVName[CE_MAX_SCALES] = {"ssim2_vblur_ssim_L0", "ssim2_vblur_ssim_L1", "ssim2_vblur_ssim_L2",
-                                                      "ssim2_vblur_ssim_L3", "ssim2_vblur_ssim_L4", "ssim2_vblur_ssim_L5"};
     using hblur_fn = void (*)(const float *, const uint32_t *, float *, uint32_t, uint32_t, uint32_t, size_t, uint32_t,
-                              rg_consts);
-    static const hblur_fn kHblur[CE_MAX_SCALES] = {k_ssim2_hblur_lds<0>, k_ssim2_hblur_lds<1>, k_ssim2_hblur_lds<2>,
-                                                   k_ssim2_hblur_lds<3>, k_ssim2_hblur_lds<4>, k_ssim2_hblur_lds<5>};
+                              rg_consts, lvl_table);
     using vblur_fn = void (*)(const float *, const float *, const uint32_t *, double *, uint32_t, uint32_t, uint32_t,
-                              size_t, uint32_t, uint32_t, uint32_t, rg_consts);
-    static const vblur_fn kVblur[CE_MAX_SCALES] = {k_ssim2_vblur_dma<0>, k_ssim2_vblur_dma<1>, k_ssim2_vblur_dma<2>,
-                                                   k_ssim2_vblur_dma<3>, k_ssim2_vblur_dma<4>, k_ssim2_vblur_dma<5>};
+                              size_t, uint32_t, uint32_t, uint32_t, rg_consts, lvl_table);
+    const hblur_fn h_l0 = k_ssim2_hblur_lds<0>, h_tail = k_ssim2_hblur_lds<-1>;
+    const vblur_fn v_l0 = k_ssim2_vblur_dma<0>, v_tail = k_ssim2_vblur_dma<-1>;
     scale_geom g{};
     const int levels = std::min(b->n_scales, b->debug_max_scales);
-    // Front end on the context's stream (level s+1 needs level s's linear planes); each level's row and
-    // column pass on that level's own stream, so the small, latency-bound levels overlap the large ones.
+    // Front end on the context's stream, level by level (level s+1 needs level s's linear planes).  Level 0's row
+    // and column pass run on their own stream as soon as level 0's planes exist; levels 1.. share ONE row-pass and
+    // ONE column-pass launch on a second stream once the whole pyramid exists, so they overlap level 0.
     // In the serial profiling mode everything stays on one stream so that per-kernel times do not overlap.
+    hipStream_t s0 = ctx->prof_serial ? ctx->stream : b->lvl_stream[0];
+    hipStream_t s1 = ctx->prof_serial ? ctx->stream : b->lvl_stream[1];
+    lvl_table tab{};
+    lvl_table tab_v{};
     for (int s = 0; s < levels; s++) {
         const ce_scale_dims &d = b->sd[s];
         const bool has_next = s + 1 < levels;
@@ -684,22 +713,49 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             CE_LAUNCH(ctx, "ssim2_prep", k_ssim2_prep<false>, quad_grid, dim3(256), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
                       (const float *)b->d_lin[s], b->d_xyb[s], b->d_lin[has_next ? s + 1 : s], d.w, d.h, d.pitch, d.plane,
                       nd.pitch, nd.plane, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs, z0);
-        hipStream_t ls = ctx->prof_serial ? ctx->stream : b->lvl_stream[s];
-        if (ls != ctx->stream) {
-            CE_HIP(ctx, hipEventRecord(b->ev_prep[s], ctx->stream));
-            CE_HIP(ctx, hipStreamWaitEvent(ls, b->ev_prep[s], 0));
-        }
-        CE_LAUNCH_ON(ctx, ls, kHName[s], kHblur[s], dim3((d.h + HB_ROWS - 1) / HB_ROWS, 3, n_pairs), dim3(HB_THREADS), 0,
-                     b->d_xyb[s], b->d_pair_ref, b->d_hbuf[s], d.w, d.h, d.pitch, d.plane, b->max_refs, rg);
-        const uint32_t nblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
-        CE_LAUNCH_ON(ctx, ls, kVName[s], kVblur[s], dim3(nblk, 3, n_pairs), dim3(64), 0, b->d_hbuf[s], b->d_xyb[s],
-                     b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, (uint32_t)s, b->max_vblocks, rg);
-        if (ls != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[s], ls));
+        const uint32_t hblk = (d.h + HB_ROWS - 1) / HB_ROWS, vblk = (d.w + kColsPerBlock - 1) / kColsPerBlock;
         g.npix[s] = d.w * d.h;
-        g.nblk[s] = nblk;
+        g.nblk[s] = vblk;
+        if (s == 0) {
+            if (s0 != ctx->stream) {
+                CE_HIP(ctx, hipEventRecord(b->ev_prep[0], ctx->stream));
+                CE_HIP(ctx, hipStreamWaitEvent(s0, b->ev_prep[0], 0));
+            }
+            CE_LAUNCH_ON(ctx, s0, "ssim2_hblur_L0", h_l0, dim3(hblk, 3, n_pairs), dim3(HB_THREADS), 0, b->d_xyb[0], b->d_pair_ref,
+                         b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab);
+            CE_LAUNCH_ON(ctx, s0, "ssim2_vblur_ssim_L0", v_l0, dim3(vblk, 3, n_pairs), dim3(64), 0, b->d_hbuf[0], b->d_xyb[0],
+                         b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab);
+            if (s0 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[0], s0));
+        } else {
+            const uint32_t l = tab.n++;
+            tab_v.n = tab.n;
+            tab.first_level = tab_v.first_level = 1;
+            tab.blk_end[l] = (l ? tab.blk_end[l - 1] : 0) + hblk;
+            tab_v.blk_end[l] = (l ? tab_v.blk_end[l - 1] : 0) + vblk;
+            tab.w[l] = tab_v.w[l] = d.w;
+            tab.h[l] = tab_v.h[l] = d.h;
+            tab.pitch[l] = tab_v.pitch[l] = d.pitch;
+            tab.plane[l] = tab_v.plane[l] = d.plane;
+            tab.xyb[l] = tab_v.xyb[l] = b->d_xyb[s];
+            tab.hbuf[l] = tab_v.hbuf[l] = b->d_hbuf[s];
+        }
     }
-    if (!ctx->prof_serial)
-        for (int s = 0; s < levels; s++) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[s], 0));
+    if (tab.n) {
+        if (s1 != ctx->stream) {
+            CE_HIP(ctx, hipEventRecord(b->ev_prep[1], ctx->stream));
+            CE_HIP(ctx, hipStreamWaitEvent(s1, b->ev_prep[1], 0));
+        }
+        CE_LAUNCH_ON(ctx, s1, "ssim2_hblur_L1-5", h_tail, dim3(tab.blk_end[tab.n - 1], 3, n_pairs), dim3(HB_THREADS), 0,
+                     (const float *)nullptr, b->d_pair_ref, (float *)nullptr, 0u, 0u, 0u, (size_t)0, b->max_refs, rg, tab);
+        CE_LAUNCH_ON(ctx, s1, "ssim2_vblur_ssim_L1-5", v_tail, dim3(tab_v.blk_end[tab_v.n - 1], 3, n_pairs), dim3(64), 0,
+                     (const float *)nullptr, (const float *)nullptr, b->d_pair_ref, b->d_partials, 0u, 0u, 0u, (size_t)0, b->max_refs,
+                     0u, b->max_vblocks, rg, tab_v);
+        if (s1 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[1], s1));
+    }
+    if (!ctx->prof_serial) {
+        CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[0], 0));
+        if (tab.n) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[1], 0));
+    }
     if (b->keep_ref_pyramid && !cached) {
         b->ssim2_ref_src = d_refs;
         b->ssim2_ref_count = n_refs_used;

@@ -200,6 +200,8 @@ void ce_ref_destroy(ce_ref *ref);
  * kernel trace sees).  on = 1: additionally keep all launches on the context's stream, one kernel at a
  * time ("solo" times). */
 int ce_prof_enable(ce_ctx *ctx, int on);
+/* restrict the events to kernels whose name contains `substring` (NULL or "" = all kernels) */
+int ce_prof_filter(ce_ctx *ctx, const char *substring);
 int ce_prof_reset(ce_ctx *ctx);
 /* number of distinct kernels seen; then per index: name, launches, total ms */
 int ce_prof_count(ce_ctx *ctx);

@@ -21,6 +21,7 @@ import re
 import sys
 
 SHORT = [
+    (r"k_ssim2_hblur_lds<-1>", "ssim2_hblur_L1-5"), (r"k_ssim2_vblur_dma<-1>", "ssim2_vblur_ssim_L1-5"),
     (r"k_ssim2_hblur_lds<(\d)>", "ssim2_hblur_L{}"), (r"k_ssim2_vblur_dma<(\d)>", "ssim2_vblur_ssim_L{}"),
     (r"k_ssim2_prep<true>", "ssim2_prep_u8"), (r"k_ssim2_prep<false>", "ssim2_prep"), (r"k_ssim2_finalize", "ssim2_finalize"),
 ]
