@@ -41,7 +41,7 @@ def one(d, suffix):
     f = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
     if not f:
         raise SystemExit(f"no *{suffix} under {d}")
-    return f[0]
+    return max(f, key=os.path.getmtime)  # gpurun merges into gpurun_out/: take the newest run
 
 
 def main():
