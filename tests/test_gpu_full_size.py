@@ -1,0 +1,61 @@
+"""Parity at BASELINE.json's full sizes.
+
+configs[2] works on 3840x2160 images: one such pair is scored by every metric and compared with the oracle directly
+(the C oracle needs ~40 s of one host core for it), and the whole config-3 batch is checked through properties that do
+not depend on size (identity, batch == single, permutation of pairs, monotonic in the distortion strength).
+configs[1]/[3]/[4] sizes (768x512, 512x768, 512x512) are compared with the oracle directly in test_gpu_parity.py /
+test_gpu_butteraugli.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 3840, 2160
+
+
+def rel(got, want, floor):
+    return abs(got - want) / max(abs(want), floor)
+
+
+def test_4k_pair_every_metric_against_the_oracle(gpu_ctx, oracle, ce, workloads):
+    g = workloads.uhd_pairs(1, seed0=2000)
+    ref, (ri, test) = g.references[0], g.pairs[0]
+    assert (g.width, g.height) == (W, H)
+    m = gpu_ctx.calculate_metrics(ref, test, W, H, ce.MetricConfig.all())
+    assert m.psnr == oracle.psnr(ref, test, W, H)  # bit-exact
+    assert rel(m.ssimulacra2, oracle.ssimulacra2(ref, test, W, H, 1), 1.0) <= 1e-4
+    assert rel(m.dssim, oracle.dssim(ref, test, W, H), 1e-6) <= 1e-4
+    want, want_p3 = oracle.butteraugli(ref, test, W, H)
+    assert rel(m.butteraugli, want, 1e-3) <= 1e-4
+    rt = gpu_ctx.xyb_roundtrip(ref, W, H)
+    assert np.array_equal(rt, oracle.xyb_roundtrip(ref, W, H))  # u8-exact on all 8.3 M pixels
+
+
+def test_4k_batch_properties(gpu_ctx, ce, workloads):
+    n = 4
+    g = workloads.uhd_pairs(n, seed0=2100)
+    cfg = ce.MetricConfig(butteraugli=True, ssimulacra2=True)
+    b = ce.Batch(gpu_ctx, W, H, n, n + 3)
+    for i, r in enumerate(g.references):
+        b.set_reference(i, r)
+    for k, (ri, t) in enumerate(g.pairs):
+        b.set_test(k, ri, t)
+    # extra slots: an identical pair, and reference 0 at two more distortion strengths
+    b.set_test(n, 0, g.references[0])
+    strong, weak = workloads.distort(g.references[0], 40), workloads.distort(g.references[0], 97)
+    b.set_test(n + 1, 0, strong)
+    b.set_test(n + 2, 0, weak)
+    s = b.run(n + 3, cfg)
+    assert all(x.status == 0 for x in s)
+    assert s[n].butteraugli == 0.0 and s[n].ssimulacra2 == 100.0  # identity
+    assert s[n + 1].butteraugli > s[0].butteraugli > s[n + 2].butteraugli > 0.0  # q40 worse than q85 worse than q97
+    assert s[n + 1].ssimulacra2 < s[0].ssimulacra2 < s[n + 2].ssimulacra2 < 100.0
+    # batch == single call, bit for bit (pairs never interact)
+    single = gpu_ctx.calculate_metrics(g.references[1], g.pairs[1][1], W, H, cfg)
+    assert (single.butteraugli, single.ssimulacra2) == (s[1].butteraugli, s[1].ssimulacra2)
+    # permuting the pairs permutes the scores
+    for k, (ri, t) in enumerate(reversed(g.pairs)):
+        b.set_test(k, ri, t)
+    s2 = b.run(n, cfg)
+    assert [(x.butteraugli, x.ssimulacra2) for x in s2] == [(x.butteraugli, x.ssimulacra2) for x in reversed(s[:n])]
+    b.close()
