@@ -34,6 +34,10 @@ struct geom {
 struct blur_kernel {
     int len;
     float k[40];
+    // 1 / (sum of the valid weights) for an output d pixels from the low / high border of a line that is at least
+    // `len` long, summed on the host in the order the pixel loop would sum them (low border: taps off-d .. len-1,
+    // high border: taps 0 .. off+d)
+    float lo[16], hi[16];
 };
 
 #define BA_XY                                                           \
@@ -103,45 +107,89 @@ __device__ __forceinline__ float border_scale(const blur_kernel &bk, int pos, in
 {
     constexpr int off = LEN / 2;
     if (pos - off >= 0 && pos + off <= n - 1) return inv_wsum;
+    if (n >= LEN) {
+        // one border only: pick the host-built scale with compile-time indices (a dynamic index into the kernel
+        // arguments would be a serialised global load per tap - it used to cost the x-border blocks ~100 us each)
+        const int d = pos < off ? pos : n - 1 - pos;
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < off; i++) s = d == i ? (pos < off ? bk.lo[i] : bk.hi[i]) : s;
+        return s;
+    }
     float weight = 0.0f;
     for (int j = max(pos - off, 0); j <= min(pos + off, n - 1); j++) weight += bk.k[j - pos + off];
     return 1.0f / weight;
 }
 
-// horizontal: block = 8 rows x 256 columns; LDS rows are padded one float per 8 so that lanes reading
-// with a stride of 8 floats hit distinct banks
+// horizontal: block = 8 rows x 256 columns.  The tile starts 16 columns left of the block whatever LEN is, so rows
+// load as aligned float4 (72 per row); LDS rows are padded one float per 8 so that lanes reading with a stride of
+// 8 floats hit distinct banks.  A thread produces 8 consecutive outputs as 4 PAIRS: its 8+LEN-1 inputs are held
+// as even-aligned pairs (v[2i], v[2i+1]) and odd-aligned pairs (v[2i+1], v[2i+2]), so every tap of an output pair
+// is one v_pk_mul_f32 + one v_pk_add_f32 (two IEEE multiplies / adds: bit-identical to the scalar tap loop, taps
+// still summed in ascending order).
+typedef float ba_f2 __attribute__((ext_vector_type(2)));
+
 template <int LEN>
 __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
                                                    plane_sel so, blur_kernel bk, float inv_wsum, uint32_t n_refs_used,
                                                    uint32_t max_refs, int by_slot)
 {
-    constexpr int off = LEN / 2, TW = 256, TR = 8, RAW = TW + LEN - 1, ROWF = RAW + RAW / 8 + 1;
+    constexpr int off = LEN / 2, TW = 256, TR = 8, LEFT = 16, RAW = TW + 2 * LEFT, ROWF = RAW + RAW / 8 + 1, SH = LEFT - off;
+    static_assert(off <= LEFT, "tile halo");
     __shared__ float tile[TR * ROWF];
     const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
     const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
     const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
-    for (int i = threadIdx.x; i < TR * RAW; i += TPB) {
-        const int r = i / RAW, c = i % RAW, gx = x0 - off + c, gy = y0 + r;
-        tile[r * ROWF + c + (c >> 3)] = (gx >= 0 && gx < (int)g.w && gy < (int)g.h) ? p[(size_t)gy * g.pitch + gx] : 0.0f;
+    for (int i = threadIdx.x; i < TR * (RAW / 4); i += TPB) {
+        const int r = i / (RAW / 4), c = 4 * (i % (RAW / 4)), gx = x0 - LEFT + c, gy = y0 + r;
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef BA_ABLATE_NOLOAD
+        if (false) {
+#else
+        if (gx >= 0 && gx < (int)g.pitch && gy < (int)g.h) {  // 16-byte aligned, whole float4 inside the padded row
+#endif
+            v = *reinterpret_cast<const float4 *>(p + (size_t)gy * g.pitch + gx);
+            if (gx + 3 >= (int)g.w) {  // the row's padding is not part of the image
+                if (gx + 0 >= (int)g.w) v.x = 0.0f;
+                if (gx + 1 >= (int)g.w) v.y = 0.0f;
+                if (gx + 2 >= (int)g.w) v.z = 0.0f;
+                v.w = 0.0f;
+            }
+        }
+        float *t = &tile[r * ROWF + c + (c >> 3)];  // c is a multiple of 4: the four floats stay inside one group of 8
+        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
     }
     __syncthreads();
     const int r = threadIdx.x >> 5, cx = threadIdx.x & 31, gy = y0 + r, gx0 = x0 + 8 * cx;
     if (gy >= (int)g.h || gx0 >= (int)g.w) return;
-    float v[BW_OUT + LEN - 1];
+    constexpr int NV = BW_OUT + LEN - 1, NP = (NV + 1) / 2;
+    const float *row = &tile[r * ROWF + 9 * cx];  // element j of the window sits at j + SH + ((j + SH) >> 3)
+    auto at = [&](int j) { return row[(j + SH) + ((j + SH) >> 3)]; };
+    ba_f2 pe[NP], po[NP];
 #pragma unroll
-    for (int j = 0; j < BW_OUT + LEN - 1; j++) {
-        const int c = 8 * cx + j;
-        v[j] = tile[r * ROWF + c + (c >> 3)];
+    for (int i = 0; i < NP; i++) {
+        pe[i] = ba_f2{at(2 * i), 2 * i + 1 < NV ? at(2 * i + 1) : 0.0f};
+        po[i] = ba_f2{2 * i + 1 < NV ? at(2 * i + 1) : 0.0f, 2 * i + 2 < NV ? at(2 * i + 2) : 0.0f};
     }
     float *dst = out + ((size_t)unit * so.per_unit + so.first + k) * g.plane + (size_t)gy * g.pitch + gx0;
     float res[BW_OUT];
 #pragma unroll
-    for (int o = 0; o < BW_OUT; o++) {
-        float sum = 0.0f;
+    for (int op = 0; op < BW_OUT / 2; op++) {
+        ba_f2 sum = {0.0f, 0.0f};
+#ifdef BA_ABLATE_NOMATH
+        sum = pe[op] + po[op + LEN / 2];
+#else
 #pragma unroll
-        for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
-        res[o] = sum * border_scale<LEN>(bk, gx0 + o, (int)g.w, inv_wsum);
+        for (int j = 0; j < LEN; j++) {
+            const int idx = 2 * op + j;
+            const ba_f2 src = (idx & 1) ? po[idx >> 1] : pe[idx >> 1];
+            const ba_f2 prod = src * ba_f2{bk.k[j], bk.k[j]};
+            sum = sum + prod;
+        }
+#endif
+        res[2 * op] = sum.x * border_scale<LEN>(bk, gx0 + 2 * op, (int)g.w, inv_wsum);
+        res[2 * op + 1] = sum.y * border_scale<LEN>(bk, gx0 + 2 * op + 1, (int)g.w, inv_wsum);
     }
     if (gx0 + BW_OUT <= (int)g.w) {  // rows are 128-byte aligned and gx0 is a multiple of 8
         *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
@@ -749,6 +797,13 @@ blur_kernel make_kernel(float sigma)
     if (diff < 1) diff = 1;
     for (int i = -diff; i <= diff; i++) bk.k[i + diff] = (float)std::exp(scaler * i * i);
     bk.len = 2 * diff + 1;
+    for (int d = 0; d < diff && d < 16; d++) {
+        float lo = 0.0f, hi = 0.0f;
+        for (int j = diff - d; j < bk.len; j++) lo += bk.k[j];
+        for (int j = 0; j <= diff + d; j++) hi += bk.k[j];
+        bk.lo[d] = 1.0f / lo;
+        bk.hi[d] = 1.0f / hi;
+    }
     return bk;
 }
 
