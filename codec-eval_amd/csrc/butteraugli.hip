@@ -634,20 +634,16 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ p
     m1[(size_t)p * g.plane + o] = mask_pre_one(psy + (size_t)(max_refs + p) * PSY * g.plane + o, g.plane);
 }
 
+// StoreMin3: keep the three smallest values seen, sorted.  The state (min0 <= min1 <= min2) starts sorted for the
+// non-negative inputs of the mask, so the insertion is a min/max network - no branches, no indexed temporaries
+// (the branchy form was compiled into a scratch-memory array).
 __device__ __forceinline__ void store_min3(float v, float &min0, float &min1, float &min2)
 {
-    if (v < min2) {
-        if (v < min0) {
-            min2 = min1;
-            min1 = min0;
-            min0 = v;
-        } else if (v < min1) {
-            min2 = min1;
-            min1 = v;
-        } else {
-            min2 = v;
-        }
-    }
+    const float a = fminf(min0, v), t = fmaxf(min0, v);
+    const float b = fminf(min1, t), u = fmaxf(min1, t);
+    min2 = fminf(min2, u);
+    min1 = b;
+    min0 = a;
 }
 
 // mask = FuzzyErosion(blurred0); ac[1] += 10 (blurred0 - blurred1)^2; then CombineChannelsToDiffmap — one pass
@@ -659,22 +655,28 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict
     BA_XY;
     const float *from = bl0 + (size_t)p * g.plane;
     const int X = (int)x, Y = (int)y, W = (int)g.w, H = (int)g.h, S = 3;
-    auto at = [&](int yy, int xx) { return from[(size_t)yy * g.pitch + xx]; };
-    float min0 = at(Y, X), min1 = 2 * min0, min2 = min1;
-    if (X >= S) {
-        store_min3(at(Y, X - S), min0, min1, min2);
-        if (Y >= S) store_min3(at(Y - S, X - S), min0, min1, min2);
-        if (Y < H - S) store_min3(at(Y + S, X - S), min0, min1, min2);
-    }
-    if (X < W - S) {
-        store_min3(at(Y, X + S), min0, min1, min2);
-        if (Y >= S) store_min3(at(Y - S, X + S), min0, min1, min2);
-        if (Y < H - S) store_min3(at(Y + S, X + S), min0, min1, min2);
-    }
-    if (Y >= S) store_min3(at(Y - S, X), min0, min1, min2);
-    if (Y < H - S) store_min3(at(Y + S, X), min0, min1, min2);
+    const uint32_t pitch = g.pitch;
+#define at(yy, xx) from[(size_t)(yy) * pitch + (xx)]
+    // FuzzyErosion: the three smallest of the centre and its eight neighbours at distance 3 that exist.  All nine
+    // loads are issued unconditionally at clamped coordinates (independent, so they overlap); a neighbour that does
+    // not exist enters as +inf, which store_min3 ignores.
+    const int xl = max(X - S, 0), xr = min(X + S, W - 1), yu = max(Y - S, 0), yd = min(Y + S, H - 1);
+    const float c0 = at(Y, X);
+    const float v_l = at(Y, xl), v_lu = at(yu, xl), v_ld = at(yd, xl), v_r = at(Y, xr), v_ru = at(yu, xr), v_rd = at(yd, xr),
+                v_u = at(yu, X), v_d = at(yd, X);
+    const bool hl = X >= S, hr = X < W - S, hu = Y >= S, hd = Y < H - S;
+    const float INF = __builtin_inff();
+    float min0 = c0, min1 = 2 * min0, min2 = min1;
+    store_min3(hl ? v_l : INF, min0, min1, min2);
+    store_min3(hl && hu ? v_lu : INF, min0, min1, min2);
+    store_min3(hl && hd ? v_ld : INF, min0, min1, min2);
+    store_min3(hr ? v_r : INF, min0, min1, min2);
+    store_min3(hr && hu ? v_ru : INF, min0, min1, min2);
+    store_min3(hr && hd ? v_rd : INF, min0, min1, min2);
+    store_min3(hu ? v_u : INF, min0, min1, min2);
+    store_min3(hd ? v_d : INF, min0, min1, min2);
     const float mask = 0.45f * min0 + 0.3f * min1 + 0.25f * min2;
-    const float mdiff = at(Y, X) - bl1[(size_t)p * g.plane + o];
+    const float mdiff = c0 - bl1[(size_t)p * g.plane + o];
 
     const double kGlobalScale = 1.0 / (17.83 * 0.790799174);
     const double val = (double)mask;
@@ -684,19 +686,17 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict
     c = 0.505054525019 / ((3.87449418804 * val) + 0.20025578522);
     rv = kGlobalScale * (1.0 + c);
     const float dc_maskval = (float)(rv * rv);
-    float d_ac[3], d_dc[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        d_ac[k] = ac[((size_t)k * n_pairs_stride + p) * g.plane + o];
-        d_dc[k] = dc[((size_t)k * n_pairs_stride + p) * g.plane + o];
-    }
-    d_ac[1] += 10.0f * mdiff * mdiff;  // kMaskToErrorMul
+#undef at
+    const size_t pl = g.plane, kp = (size_t)n_pairs_stride * pl, po = (size_t)p * pl + o;
+    float ac0 = ac[po], ac1 = ac[kp + po], ac2 = ac[2 * kp + po];
+    float dc0 = dc[po], dc1 = dc[kp + po], dc2 = dc[2 * kp + po];
+    ac1 += 10.0f * mdiff * mdiff;  // kMaskToErrorMul
     const float xmul = 1.0f;
-    d_ac[0] *= xmul;
-    d_dc[0] *= xmul;
-    const float mc_dc = d_dc[0] * dc_maskval + d_dc[1] * dc_maskval + d_dc[2] * dc_maskval;
-    const float mc_ac = d_ac[0] * maskval + d_ac[1] * maskval + d_ac[2] * maskval;
-    diffmap[(size_t)p * g.plane + o] = sqrtf(mc_dc + mc_ac);
+    ac0 *= xmul;
+    dc0 *= xmul;
+    const float mc_dc = dc0 * dc_maskval + dc1 * dc_maskval + dc2 * dc_maskval;
+    const float mc_ac = ac0 * maskval + ac1 * maskval + ac2 * maskval;
+    diffmap[po] = sqrtf(mc_dc + mc_ac);
 }
 
 // AddSupersampled2x (weight 0.5) fused with the final reductions: max, sum d^3, d^6, d^12
