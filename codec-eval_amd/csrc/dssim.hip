@@ -63,9 +63,18 @@ __device__ __forceinline__ void rgb_to_lab(float r, float g, float b, float &L, 
 // (gx0, gy0).  The centre (lx, ly) must be inside the image; neighbours are clamped in GLOBAL coordinates,
 // which is exactly "replicate the edge of that pass's input".  SQ squares every tap (blur of the squared
 // image).  Summation order as in oracle/dssim.c: corners, edges, centre.
-template <int RW, bool SQ>
+// INTERIOR: the whole region lies inside the image (block-uniform), so no neighbour is clamped and the nine taps
+// are LDS reads at constant offsets from the centre.
+template <int RW, bool SQ, bool INTERIOR = false>
 __device__ __forceinline__ float pass3x3(const float *__restrict__ A, int lx, int ly, int gx0, int gy0, int w, int h)
 {
+    if (INTERIOR) {
+        const float *c = A + ly * RW + lx;
+        auto sqv = [](float v) { return SQ ? v * v : v; };
+        const float K0 = 0.095332f, K1 = 0.118095f, K4 = 0.146293f;
+        return (sqv(c[-RW - 1]) + sqv(c[-RW + 1]) + sqv(c[RW - 1]) + sqv(c[RW + 1])) * K0 +
+               (sqv(c[-RW]) + sqv(c[-1]) + sqv(c[1]) + sqv(c[RW])) * K1 + sqv(c[0]) * K4;
+    }
     const int X = gx0 + lx, Y = gy0 + ly;
     const int xm = max(X - 1, 0) - gx0, xp = min(X + 1, w - 1) - gx0;
     const int ym = max(Y - 1, 0) - gy0, yp = min(Y + 1, h - 1) - gy0;
@@ -88,6 +97,81 @@ struct lvl_geom {
 // mu = blur(img) (2 passes), sq = blur(img*img) (2 passes); also the next level's linear RGB.
 // Writes img, mu, sq (9 planes) for the tile; every intermediate lives in LDS only.
 constexpr int DT = 32, DR = DT + 8;
+
+// stages S1..S4 of k_dssim_create on the LDS planes; IN = the block's whole 40x40 region is inside the image
+template <bool IN>
+__device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], float *__restrict__ img, float *__restrict__ mu,
+                                                    float *__restrict__ sq, const lvl_geom &g, uint32_t slot, int x0, int y0)
+{
+    const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 4, gy0 = y0 - 4;
+    auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
+    // Six LDS planes are enough (38 KB, four blocks per CU instead of two): planes are reused as soon as their
+    // contents are dead, and mu / sq are produced one after the other through the same three planes.
+    // S1: chroma pre-blur pass 1 (margin 1): P1,P2 -> P3,P4
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 1 && lx < DR - 1 && ly >= 1 && ly < DR - 1 && (IN || inside(lx, ly))) {
+            P[3][i] = pass3x3<DR, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<DR, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S2: chroma pre-blur pass 2 (margin 2): P3,P4 -> P1,P2 (their old contents are dead) ; img = (P0, P1, P2)
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 2 && lx < DR - 2 && ly >= 2 && ly < DR - 2 && (IN || inside(lx, ly))) {
+            P[1][i] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
+            P[2][i] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S3a: first pass of mu (margin 3): img -> P3,P4,P5
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 3 && lx < DR - 3 && ly >= 3 && ly < DR - 3 && (IN || inside(lx, ly))) {
+            P[3][i] = pass3x3<DR, false, IN>(P[0], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<DR, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
+            P[5][i] = pass3x3<DR, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S4a: second pass of mu on the tile itself; write img and mu
+    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+        const int tx = i % DT, ty = i / DT, lx = tx + 4, ly = ty + 4, X = x0 + tx, Y = y0 + ty;
+        if (IN || (X < w && Y < h)) {
+            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
+            const int li = ly * DR + lx;
+            img[o] = P[0][li];
+            img[o + g.plane] = P[1][li];
+            img[o + 2 * g.plane] = P[2][li];
+            mu[o] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
+            mu[o + g.plane] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
+            mu[o + 2 * g.plane] = pass3x3<DR, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S3b: first pass of sq = blur(img * img): img -> P3,P4,P5
+    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
+        const int lx = i % DR, ly = i / DR;
+        if (lx >= 3 && lx < DR - 3 && ly >= 3 && ly < DR - 3 && (IN || inside(lx, ly))) {
+            P[3][i] = pass3x3<DR, true, IN>(P[0], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<DR, true, IN>(P[1], lx, ly, gx0, gy0, w, h);
+            P[5][i] = pass3x3<DR, true, IN>(P[2], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // S4b: second pass of sq; write sq
+    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+        const int tx = i % DT, ty = i / DT, lx = tx + 4, ly = ty + 4, X = x0 + tx, Y = y0 + ty;
+        if (IN || (X < w && Y < h)) {
+            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
+            sq[o] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
+            sq[o + g.plane] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
+            sq[o + 2 * g.plane] = pass3x3<DR, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
+        }
+    }
+}
+
 template <bool FROM_U8>
 __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
                                                       const float *__restrict__ lut, const float *__restrict__ lin_in,
@@ -95,7 +179,7 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
                                                       float *__restrict__ sq, lvl_geom g, lvl_geom gn, int has_next,
                                                       size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
 {
-    __shared__ float P[9][DR * DR];
+    __shared__ float P[6][DR * DR];
     __shared__ float s_lut[256];
     if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
     const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
@@ -139,55 +223,12 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
         }
     }
     __syncthreads();
-    auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
-    // S1: chroma pre-blur pass 1 (margin 1): P1,P2 -> P3,P4
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 1 && lx < DR - 1 && ly >= 1 && ly < DR - 1 && inside(lx, ly)) {
-            P[3][i] = pass3x3<DR, false>(P[1], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<DR, false>(P[2], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S2: chroma pre-blur pass 2 (margin 2): P3,P4 -> P5,P6 ; img = (P0, P5, P6)
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 2 && lx < DR - 2 && ly >= 2 && ly < DR - 2 && inside(lx, ly)) {
-            P[5][i] = pass3x3<DR, false>(P[3], lx, ly, gx0, gy0, w, h);
-            P[6][i] = pass3x3<DR, false>(P[4], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S3: first pass of mu and sq (margin 3): img -> P1,P2,P3 (mu) and P4,P7,P8 (sq)
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 3 && lx < DR - 3 && ly >= 3 && ly < DR - 3 && inside(lx, ly)) {
-            P[1][i] = pass3x3<DR, false>(P[0], lx, ly, gx0, gy0, w, h);
-            P[2][i] = pass3x3<DR, false>(P[5], lx, ly, gx0, gy0, w, h);
-            P[3][i] = pass3x3<DR, false>(P[6], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<DR, true>(P[0], lx, ly, gx0, gy0, w, h);
-            P[7][i] = pass3x3<DR, true>(P[5], lx, ly, gx0, gy0, w, h);
-            P[8][i] = pass3x3<DR, true>(P[6], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S4: second pass on the tile itself; write img, mu, sq
-    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-        const int tx = i % DT, ty = i / DT, lx = tx + 4, ly = ty + 4, X = x0 + tx, Y = y0 + ty;
-        if (X < w && Y < h) {
-            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-            const int li = ly * DR + lx;
-            img[o] = P[0][li];
-            img[o + g.plane] = P[5][li];
-            img[o + 2 * g.plane] = P[6][li];
-            mu[o] = pass3x3<DR, false>(P[1], lx, ly, gx0, gy0, w, h);
-            mu[o + g.plane] = pass3x3<DR, false>(P[2], lx, ly, gx0, gy0, w, h);
-            mu[o + 2 * g.plane] = pass3x3<DR, false>(P[3], lx, ly, gx0, gy0, w, h);
-            sq[o] = pass3x3<DR, false>(P[4], lx, ly, gx0, gy0, w, h);
-            sq[o + g.plane] = pass3x3<DR, false>(P[7], lx, ly, gx0, gy0, w, h);
-            sq[o + 2 * g.plane] = pass3x3<DR, false>(P[8], lx, ly, gx0, gy0, w, h);
-        }
-    }
+    // S1..S4 (two chroma pre-blur passes, two passes each for mu and sq, stores): a block whose 40x40 region is
+    // wholly inside the image takes the variant without clamping or bounds tests
+    if (gx0 >= 0 && gy0 >= 0 && gx0 + DR <= w && gy0 + DR <= h)
+        dssim_create_stages<true>(P, img, mu, sq, g, slot, x0, y0);
+    else
+        dssim_create_stages<false>(P, img, mu, sq, g, slot, x0, y0);
 }
 
 __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -205,6 +246,51 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
 
 // ---- Dssim::compare for one level, fused: i12 = blur(img1*img2) in LDS (tile + halo 2), then compare_scale ----
 constexpr int CR = DT + 4;
+
+// the blur of img1*img2 (second pass) and compare_scale on the LDS planes; IN = the block's 36x36 region is inside the image
+template <bool IN>
+__device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], float (&T)[3][CR * CR], const float *__restrict__ mu,
+                                                       const float *__restrict__ sq, float *__restrict__ map, const lvl_geom &g,
+                                                       size_t sa, size_t sb, uint32_t p, int x0, int y0)
+{
+    const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 2, gy0 = y0 - 2;
+    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
+        const int lx = i % CR, ly = i / CR;
+        if (lx >= 1 && lx < CR - 1 && ly >= 1 && ly < CR - 1 && (IN || (gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h))) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, false, IN>(M[c], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    double val = 0.0;
+    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+        const int tx = i % DT, ty = i / DT, lx = tx + 2, ly = ty + 2, X = x0 + tx, Y = y0 + ty;
+        if (IN || (X < w && Y < h)) {
+            const size_t o = (size_t)Y * g.pitch + X;
+            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
+            float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float u1 = mu[sa + c * g.plane + o], u2 = mu[sb + c * g.plane + o];
+                m11[c] = u1 * u1;
+                m12[c] = u1 * u2;
+                m22[c] = u2 * u2;
+                s1[c] = sq[sa + c * g.plane + o] - m11[c];
+                s2[c] = sq[sb + c * g.plane + o] - m22[c];
+                s12[c] = pass3x3<CR, false, IN>(T[c], lx, ly, gx0, gy0, w, h) - m12[c];
+            }
+#define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
+            const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
+            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12);
+#undef AVG3
+            const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
+            map[(size_t)p * g.plane + o] = ssim;
+            val += (double)ssim;
+        }
+    }
+    return val;
+}
+
 __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ mu,
                                                        const float *__restrict__ sq, const uint32_t *__restrict__ pair_ref,
                                                        float *__restrict__ map, double *__restrict__ part, lvl_geom g,
@@ -224,40 +310,9 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
         for (int c = 0; c < 3; c++) M[c][i] = img[sa + c * g.plane + o] * img[sb + c * g.plane + o];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
-        const int lx = i % CR, ly = i / CR;
-        if (lx >= 1 && lx < CR - 1 && ly >= 1 && ly < CR - 1 && gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, false>(M[c], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    double val = 0.0;
-    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-        const int tx = i % DT, ty = i / DT, lx = tx + 2, ly = ty + 2, X = x0 + tx, Y = y0 + ty;
-        if (X < w && Y < h) {
-            const size_t o = (size_t)Y * g.pitch + X;
-            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
-            float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float u1 = mu[sa + c * g.plane + o], u2 = mu[sb + c * g.plane + o];
-                m11[c] = u1 * u1;
-                m12[c] = u1 * u2;
-                m22[c] = u2 * u2;
-                s1[c] = sq[sa + c * g.plane + o] - m11[c];
-                s2[c] = sq[sb + c * g.plane + o] - m22[c];
-                s12[c] = pass3x3<CR, false>(T[c], lx, ly, gx0, gy0, w, h) - m12[c];
-            }
-#define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
-            const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
-            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12);
-#undef AVG3
-            const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
-            map[(size_t)p * g.plane + o] = ssim;
-            val += (double)ssim;
-        }
-    }
+    const double val = (gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h)
+                           ? dssim_compare_stages<true>(M, T, mu, sq, map, g, sa, sb, p, x0, y0)
+                           : dssim_compare_stages<false>(M, T, mu, sq, map, g, sa, sb, p, x0, y0);
     const double t = block_sum(val, s_red);
     if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
