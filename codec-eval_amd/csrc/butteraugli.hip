@@ -352,73 +352,103 @@ __device__ __forceinline__ float maximum_clamp(float v, float maxval)
     return v;
 }
 
-// mf_raw = xyb - lf  (into the three MF planes of the psycho image)
-__global__ __launch_bounds__(TPB) void k_ba_mf_raw(const float *__restrict__ xyb, float *__restrict__ psy, geom g,
-                                                   uint32_t n_refs_used, uint32_t max_refs)
-{
-    const uint32_t slot = slot_of(blockIdx.z / 3, n_refs_used, max_refs), c = blockIdx.z % 3;
-    BA_XY;
-    float *ps = psy + (size_t)slot * PSY * g.plane + o;
-    ps[(MF0 + c) * g.plane] = xyb[((size_t)slot * 3 + c) * g.plane + o] - ps[(LF0 + c) * g.plane];
-}
+// ---- column blur of all planes of one image slot + the pointwise stage that consumes them, fused ---------------
+// SeparateFrequencies alternates a blur with a pointwise split; as separate kernels every split re-reads the blur's
+// output and the band it splits.  Here a block blurs the NP planes of its 64 x 32 tile one after the other (same
+// LDS tile, results kept in registers) and then runs the split on registers, reading only the raw band:
+//   EPI_LF (3 planes, sigma 7.156): lf = blur(xyb);  mf_raw = xyb - lf -> psy MF;  XybLowFreqToVals(lf) -> psy LF
+//   EPI_MF (3 planes, sigma 3.225): mf = blur(mf_raw);  hf_raw = mf_raw - mf (X suppressed by Y) -> psy HF;
+//                                   range-shaped mf -> psy MF
+//   EPI_HF (2 planes, sigma 1.564): hf = blur(hf_raw);  uhf = hf_raw - hf, clamps / ranges -> psy UHF, HF
+// Arithmetic per element is exactly that of k_ba_blur_v followed by the old pointwise kernels.
+enum { EPI_LF = 0, EPI_MF = 1, EPI_HF = 2 };
 
-// mf_raw (psy MF) and mf_blur (scratch) -> hf_raw, shaped mf; X gets SuppressXByY; B keeps the blur only
-__global__ __launch_bounds__(TPB) void k_ba_split_mf(const float *__restrict__ mf_blur, float *__restrict__ psy, geom g,
-                                                     uint32_t n_refs_used, uint32_t max_refs)
+template <int LEN, int EPI>
+__global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict__ tmp, const float *__restrict__ xyb,
+                                                         float *__restrict__ psy, geom g, blur_kernel bk, float inv_wsum,
+                                                         uint32_t n_refs_used, uint32_t max_refs)
 {
+    constexpr int NP = EPI == EPI_HF ? 2 : 3;
+    constexpr int off = LEN / 2, TW = 64, TR = 32, RAW = TR + LEN - 1;
+    __shared__ float tile[RAW * TW];
     const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
-    BA_XY;
-    float *ps = psy + (size_t)slot * PSY * g.plane + o;
-    const float *mb = mf_blur + (size_t)slot * 3 * g.plane + o;
-    const float kRemoveMfRange = 0.29f, kAddMfRange = 0.1f;
-    float hf[2];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    const int c = threadIdx.x & 63, wv = threadIdx.x >> 6, gx = x0 + c, gy0 = y0 + 8 * wv;
+    const bool live = gx < (int)g.w && gy0 < (int)g.h;
+    float res[NP][BW_OUT];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-        float mf = mb[c * g.plane];
-        hf[c] = ps[(MF0 + c) * g.plane] - mf;
-        mf = c == 0 ? remove_range(kRemoveMfRange, mf) : amplify_range(kAddMfRange, mf);
-        ps[(MF0 + c) * g.plane] = mf;
+    for (int q = 0; q < NP; q++) {
+        const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes of this slot
+        if (q) __syncthreads();
+        for (int i = threadIdx.x; i < RAW * TW; i += TPB) {
+            const int r = i / TW, cc = i % TW, X = x0 + cc, Y = y0 - off + r;
+            tile[i] = (Y >= 0 && Y < (int)g.h && X < (int)g.w) ? p[(size_t)Y * g.pitch + X] : 0.0f;
+        }
+        __syncthreads();
+        if (live) {
+            float v[BW_OUT + LEN - 1];
+#pragma unroll
+            for (int j = 0; j < BW_OUT + LEN - 1; j++) v[j] = tile[(8 * wv + j) * TW + c];
+#pragma unroll
+            for (int o = 0; o < BW_OUT; o++) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
+                res[q][o] = sum * border_scale<LEN>(bk, gy0 + o, (int)g.h, inv_wsum);
+            }
+        }
     }
-    ps[MF2 * g.plane] = mb[2 * g.plane];
-    // SuppressXByY(hf[1], &hf[0])
-    const float suppress = 46.0f, s = 0.653020556257f, one_minus_s = 1.0f - 0.653020556257f;
-    const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf[1], hf[1], suppress), one_minus_s, s);
-    ps[HF0 * g.plane] = scaler * hf[0];
-    ps[HF1 * g.plane] = hf[1];
-}
-
-// hf_raw (psy HF) and hf_blur (scratch, 2 planes per slot) -> hf, uhf
-__global__ __launch_bounds__(TPB) void k_ba_split_hf(const float *__restrict__ hf_blur, float *__restrict__ psy, geom g,
-                                                     uint32_t n_refs_used, uint32_t max_refs)
-{
-    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
-    BA_XY;
-    float *ps = psy + (size_t)slot * PSY * g.plane + o;
-    const float *hb = hf_blur + (size_t)slot * 3 * g.plane + o;
-    const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
-    const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
-    {
-        float hf = hb[0];
-        float uhf = ps[HF0 * g.plane] - hf;
-        ps[HF0 * g.plane] = remove_range(kRemoveHfRange, hf);
-        ps[UHF0 * g.plane] = remove_range(kRemoveUhfRange, uhf);
+    if (!live) return;
+    float *ps = psy + (size_t)slot * PSY * g.plane + (size_t)gy0 * g.pitch + gx;
+    const size_t pl = g.plane;
+#pragma unroll
+    for (int o = 0; o < BW_OUT; o++) {
+        if (gy0 + o >= (int)g.h) break;
+        float *q = ps + (size_t)o * g.pitch;
+        if (EPI == EPI_LF) {
+            const float *xs = xyb + (size_t)slot * 3 * pl + (size_t)(gy0 + o) * g.pitch + gx;
+            const float lx = res[0][o], ly = res[1][o], lb = res[2][o];
+            q[MF0 * pl] = xs[0] - lx;
+            q[MF1 * pl] = xs[pl] - ly;
+            q[MF2 * pl] = xs[2 * pl] - lb;
+            // XybLowFreqToVals
+            const float xmul = 33.832837186260f, ymul = 14.458268100570f, bmul = 49.87984651440f, y_to_b_mul = -0.362267051518f;
+            const float bb = __builtin_fmaf(y_to_b_mul, ly, lb);
+            q[LF2 * pl] = bb * bmul;
+            q[LF0 * pl] = lx * xmul;
+            q[LF1 * pl] = ly * ymul;
+        } else if (EPI == EPI_MF) {
+            const float kRemoveMfRange = 0.29f, kAddMfRange = 0.1f;
+            const float mf0 = res[0][o], mf1 = res[1][o];
+            const float hf0 = q[MF0 * pl] - mf0, hf1 = q[MF1 * pl] - mf1;
+            q[MF0 * pl] = remove_range(kRemoveMfRange, mf0);
+            q[MF1 * pl] = amplify_range(kAddMfRange, mf1);
+            q[MF2 * pl] = res[2][o];
+            // SuppressXByY(hf[1], &hf[0])
+            const float suppress = 46.0f, sv = 0.653020556257f, one_minus_s = 1.0f - 0.653020556257f;
+            const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf1, hf1, suppress), one_minus_s, sv);
+            q[HF0 * pl] = scaler * hf0;
+            q[HF1 * pl] = hf1;
+        } else {
+            const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
+            const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
+            {
+                const float hf = res[0][o];
+                const float uhf = q[HF0 * pl] - hf;
+                q[HF0 * pl] = remove_range(kRemoveHfRange, hf);
+                q[UHF0 * pl] = remove_range(kRemoveUhfRange, uhf);
+            }
+            {
+                float hf = maximum_clamp(res[1][o], kMaxclampHf);
+                float uhf = q[HF1 * pl] - hf;
+                uhf = maximum_clamp(uhf, kMaxclampUhf);
+                uhf *= kMulYUhf;
+                q[UHF1 * pl] = uhf;
+                hf *= kMulYHf;
+                q[HF1 * pl] = amplify_range(kAddHfRange, hf);
+            }
+        }
     }
-    {
-        float hf = maximum_clamp(hb[g.plane], kMaxclampHf);
-        float uhf = ps[HF1 * g.plane] - hf;
-        uhf = maximum_clamp(uhf, kMaxclampUhf);
-        uhf *= kMulYUhf;
-        ps[UHF1 * g.plane] = uhf;
-        hf *= kMulYHf;
-        ps[HF1 * g.plane] = amplify_range(kAddHfRange, hf);
-    }
-    // XybLowFreqToVals, in place on lf
-    const float xmul = 33.832837186260f, ymul = 14.458268100570f, bmul = 49.87984651440f, y_to_b_mul = -0.362267051518f;
-    const float lx = ps[LF0 * g.plane], ly = ps[LF1 * g.plane], lb = ps[LF2 * g.plane];
-    const float bb = __builtin_fmaf(y_to_b_mul, ly, lb);
-    ps[LF2 * g.plane] = bb * bmul;
-    ps[LF0 * g.plane] = lx * xmul;
-    ps[LF1 * g.plane] = ly * ymul;
 }
 
 // ---- per pair: Malta ----------------------------------------------------------------------------------------
@@ -924,7 +954,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         const geom g{d.w, d.h, d.pitch, d.plane};
         const dim3 gx((d.w + 63) / 64, (d.h + 3) / 4, 1);
         auto G = [&](uint32_t z) { return dim3(gx.x, gx.y, z); };
-        float *lin = b->ba_lin[l], *psy = b->ba_psy[l], *sA = b->ba_s[0], *sB = b->ba_s[1], *sC = b->ba_s[2];
+        float *lin = b->ba_lin[l], *psy = b->ba_psy[l], *sA = b->ba_s[0], *sC = b->ba_s[2];
         // ---- per image slot: PsychoImage ----
         const plane_sel s3{3, 0, 3};
         const dim3 ft((d.w + FT - 1) / FT, (d.h + FT - 1) / FT, n_slots);
@@ -939,15 +969,28 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                       sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr);
         }
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
-        const plane_sel sLf{PSY, LF0, 3}, sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
-        if ((rc = launch_blur(ctx, sC, sA, psy, g, s3, s3, sLf, kLf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "ba_mf_raw", k_ba_mf_raw, G(n_slots * 3), dim3(TPB), 0, sC, psy, g, n_refs_used, mr);
-        // MF = blur(mf_raw, 3.225) -> sB ; split
-        if ((rc = launch_blur(ctx, psy, sA, sB, g, sMf, s3, s3, kHf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "ba_split_mf", k_ba_split_mf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
-        // HF = blur(hf_raw, 1.564) -> sB[0..1] ; split
-        if ((rc = launch_blur(ctx, psy, sA, sB, g, sHf, s2, s2, kUhf, n_slots, n_refs_used, mr, 1)) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "ba_split_hf", k_ba_split_hf, G(n_slots), dim3(TPB), 0, sB, psy, g, n_refs_used, mr);
+        const plane_sel sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
+        // SeparateFrequencies: row blur of a band, then column blur fused with the pointwise split (k_ba_blur_v_split)
+        {
+            if (kLf.len != 33 || kHf.len != 15 || kUhf.len != 7) {
+                ctx->err = "unexpected blur kernel length";
+                return CE_ERR_BACKEND;
+            }
+            const dim3 gh3((g.w + 255) / 256, (g.h + 7) / 8, n_slots * 3), gh2(gh3.x, gh3.y, n_slots * 2);
+            const dim3 gvs((g.w + 63) / 64, (g.h + 31) / 32, n_slots);
+            CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
+                      n_refs_used, mr, 1);
+            CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy, g,
+                      kLf, inv_weight_sum(kLf), n_refs_used, mr);
+            CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<15>, gh3, dim3(TPB), 0, (const float *)psy, sA, g, sMf, s3, kHf, inv_weight_sum(kHf),
+                      n_refs_used, mr, 1);
+            CE_LAUNCH(ctx, "ba_blur_v_mf", (k_ba_blur_v_split<15, EPI_MF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
+                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr);
+            CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<7>, gh2, dim3(TPB), 0, (const float *)psy, sA, g, sHf, s2, kUhf, inv_weight_sum(kUhf),
+                      n_refs_used, mr, 1);
+            CE_LAUNCH(ctx, "ba_blur_v_hf", (k_ba_blur_v_split<7, EPI_HF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
+                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr);
+        }
 
         // ---- per pair ----
         float *ac = b->ba_pp[1], *dc = b->ba_pp[2], *m0 = b->ba_pp[3], *m1 = b->ba_pp[4],
