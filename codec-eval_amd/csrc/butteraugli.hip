@@ -144,11 +144,7 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
     for (int i = threadIdx.x; i < TR * (RAW / 4); i += TPB) {
         const int r = i / (RAW / 4), c = 4 * (i % (RAW / 4)), gx = x0 - LEFT + c, gy = y0 + r;
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#ifdef BA_ABLATE_NOLOAD
-        if (false) {
-#else
         if (gx >= 0 && gx < (int)g.pitch && gy < (int)g.h) {  // 16-byte aligned, whole float4 inside the padded row
-#endif
             v = *reinterpret_cast<const float4 *>(p + (size_t)gy * g.pitch + gx);
             if (gx + 3 >= (int)g.w) {  // the row's padding is not part of the image
                 if (gx + 0 >= (int)g.w) v.x = 0.0f;
@@ -177,9 +173,6 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
 #pragma unroll
     for (int op = 0; op < BW_OUT / 2; op++) {
         ba_f2 sum = {0.0f, 0.0f};
-#ifdef BA_ABLATE_NOMATH
-        sum = pe[op] + po[op + LEN / 2];
-#else
 #pragma unroll
         for (int j = 0; j < LEN; j++) {
             const int idx = 2 * op + j;
@@ -187,7 +180,6 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
             const ba_f2 prod = src * ba_f2{bk.k[j], bk.k[j]};
             sum = sum + prod;
         }
-#endif
         res[2 * op] = sum.x * border_scale<LEN>(bk, gx0 + 2 * op, (int)g.w, inv_wsum);
         res[2 * op + 1] = sum.y * border_scale<LEN>(bk, gx0 + 2 * op + 1, (int)g.w, inv_wsum);
     }
