@@ -141,6 +141,7 @@ _PROTOTYPES = [
     ("ce_debug_ssim2_planes", _i, [_vp, _i, _i, _i, _vp, _sz, C.POINTER(_u32), C.POINTER(_u32)]),
     ("ce_debug_ssim2_limit_scales", _i, [_vp, _i]),
     ("ce_debug_ssim2_averages", _i, [_vp, _u32, _dp, C.POINTER(_i)]),
+    ("ce_debug_ssim2_occupancy", _i, [_i]),
     ("ce_debug_cbrt_sweep", _i, [_vp, _u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 ]
 ABI_SYMBOLS = [p[0] for p in _PROTOTYPES]

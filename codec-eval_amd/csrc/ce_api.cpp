@@ -955,6 +955,8 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg, int *
     return CE_OK;
 }
 
+int ce_debug_ssim2_occupancy(int which) { return ce_ssim2_occupancy(which); }
+
 int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path)
 {
     if (!ctx || count == 0 || (uint64_t)first_bits + count > (1ull << 32)) return CE_ERR_INVALID_ARG;

@@ -219,77 +219,98 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // ---- row pass, LDS-staged line tiles ------------------------------------------------------
-// One block = 64 rows of one (pair, channel); wave s (0..4) runs stream s of
-// {a, b, a*a, b*b, a*b} with one row per lane, so every lane carries one 3-section filter
-// state.  Columns advance in chunks of 32.  The chunk's a/b values are fetched with coalesced
-// 16-byte row loads into registers two chunks ahead of the filter, then laid into LDS
-// column-major ([column][row], row stride 65 -> the per-lane row access is conflict-free).
-// The LDS input tile holds two 32-column halves: the chunk being filtered and the previous
-// one, which supplies the filter's left tap (10 columns back) for the first 10 steps, so all
-// LDS offsets are compile-time constants.  Outputs leave through a second LDS tile as
-// coalesced 16-byte row stores.
-constexpr int HB_ROWS = 64, HB_CW = 32, HB_LD = 65, HB_THREADS = 64 * CE_SSIM2_STREAMS;
+// One block = 48 rows of one (pair, channel) and 256 threads: thread t < 240 owns one (stream, row) pair -
+// stream t / 48 of {a, b, a*a, b*b, a*b}, row t % 48 - and carries that row's 3-section filter state.
+// (Five 64-lane waves, one per stream, look more natural, but a 320-thread block with this much LDS gets ONE
+// resident block per CU on gfx950 - measured with a spin kernel - and then SIMD0 hosts two of its five waves
+// while the other SIMDs idle half the time; 256-thread blocks get two per CU.)
+// Columns advance in chunks of 32.  The chunk's a/b values are fetched with coalesced 16-byte row loads into
+// registers ahead of the filter, then laid into LDS column-major ([column][row], row stride 49 -> per-lane row
+// access without bank conflicts inside a stream).  The LDS input tile holds two 32-column halves (double buffer);
+// outputs leave through a second LDS tile as coalesced 16-byte row stores of whole 128-byte lines.
+constexpr int HB_ROWS = 48, HB_CW = 32, HB_LD = HB_ROWS + 1, HB_THREADS = 256;
 constexpr int HB_HALF = HB_CW * HB_LD;
+constexpr int HB_TASKS = HB_ROWS * CE_SSIM2_STREAMS;  // 240 (stream, row) lanes
+constexpr int HB_STORES = CE_SSIM2_STREAMS * HB_ROWS * (HB_CW / 4);  // float4 stores per chunk: 1920
 
 // Every stream is in[i] = P[i] * Q[i] with (P, Q) = (a, 1), (b, 1), (a, a), (b, b), (a, b).
 // One chunk = 32 filter steps: step e consumes the tile's column e (right tap) and the input 10 steps
-// back (left tap, kept in a register delay line) and emits one output.
-template <bool PLAIN>
-__device__ __forceinline__ void hblur_chunk(const float *__restrict__ p_cur, const float *__restrict__ q_cur,
-                                            float *__restrict__ so, float (&dp)[10], float (&dq)[10], float (&prev)[3],
-                                            float (&prev2)[3], const rg_consts &rg)
+// back (left tap, kept in a register delay line - for the product streams the delay line holds the
+// PRODUCT, so each product is formed once) and emits one output.  The three second-order sections run
+// as one packed pair (sections 0, 1: v_pk_mul / v_pk_add / v_pk_fma, two IEEE operations each) plus one
+// scalar section - the same operations as rg_step(), in the same order.
+typedef float hb_f2 __attribute__((ext_vector_type(2)));
+
+struct hblur_state {
+    hb_f2 p01, q01;  // prev / prev2 of sections 0 and 1
+    float p2, q2;    // ... of section 2
+    float d[10];     // the last 10 inputs: slot e % 10 holds input e - 10
+};
+
+__device__ __forceinline__ void hblur_chunk(const float *__restrict__ p_cur, const float *__restrict__ q_cur, bool plain,
+                                            float *__restrict__ so, hblur_state &st, const rg_consts &rg)
 {
-    // dp/dq: the last 10 inputs (a 10-deep delay line in registers): slot e % 10 holds input e - 10
+    const hb_f2 n01 = {rg.mul_in[0], rg.mul_in[1]}, d01 = {rg.mul_prev[0], rg.mul_prev[1]};
+    // The chunk's inputs are lifted out of LDS 16 columns at a time BEFORE the steps that use them: left to the
+    // compiler, every step's ds_read sits behind the previous step's ds_write (same address space, possible alias)
+    // and is followed by s_waitcnt lgkmcnt(0) - 32 exposed LDS round trips per chunk.
 #pragma unroll
-    for (int e = 0; e < HB_CW; e++) {
-        const float pr = p_cur[e * HB_LD];
-        const float pl = dp[e % 10];
-        dp[e % 10] = pr;
-        float sum;
-        if (PLAIN) {
-            sum = pl + pr;
-        } else {
-            const float qr = q_cur[e * HB_LD];
-            const float ql = dq[e % 10];
-            dq[e % 10] = qr;
-            sum = pl * ql + pr * qr;
+    for (int half = 0; half < 2; half++) {
+        float in[HB_CW / 2];
+#pragma unroll
+        for (int i = 0; i < HB_CW / 2; i++) in[i] = p_cur[(half * (HB_CW / 2) + i) * HB_LD];
+#pragma unroll
+        for (int i = 0; i < HB_CW / 2; i++) {
+            const float q = q_cur[(half * (HB_CW / 2) + i) * HB_LD];
+            in[i] = in[i] * (plain ? 1.0f : q);  // x * 1.0f == x exactly: the plain streams are untouched
         }
-        so[e * HB_LD] = rg_step(sum, prev, prev2, rg);
+#pragma unroll
+        for (int i = 0; i < HB_CW / 2; i++) {
+            const int e = half * (HB_CW / 2) + i;
+            const float sum = st.d[e % 10] + in[i];  // left tap + right tap
+            st.d[e % 10] = in[i];
+            // rg_step(): v = sum * n2; v = v - prev2; v = fma(d1, prev, v)
+            hb_f2 v01 = hb_f2{sum, sum} * n01;
+            v01 = v01 - st.q01;
+            st.q01 = st.p01;
+            v01 = __builtin_elementwise_fma(d01, st.p01, v01);
+            st.p01 = v01;
+            float v2 = sum * rg.mul_in[2];
+            v2 = v2 - st.q2;
+            st.q2 = st.p2;
+            v2 = __builtin_fmaf(rg.mul_prev[2], st.p2, v2);
+            st.p2 = v2;
+            so[e * HB_LD] = v01.x + v01.y + v2;
+        }
     }
     // 32 steps advance the ring phase by 2: rotate so that the next chunk starts at slot 0 again
-    float tp[10], tq[10];
+    float t[10];
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-        tp[j] = dp[(j + HB_CW) % 10];
-        tq[j] = dq[(j + HB_CW) % 10];
-    }
+    for (int j = 0; j < 10; j++) t[j] = st.d[(j + HB_CW) % 10];
 #pragma unroll
-    for (int j = 0; j < 10; j++) {
-        dp[j] = tp[j];
-        if (!PLAIN) dq[j] = tq[j];
-    }
+    for (int j = 0; j < 10; j++) st.d[j] = t[j];
 }
 
-// Plane geometry (all planar f32 buffers): rows padded to a multiple of 64, pitch = 32 * ceil(w/32)
-// + 32, so every row load / store of a block is in bounds without a branch (branch-free memory
-// operations let the compiler count outstanding requests instead of draining them).
+// Plane geometry (all planar f32 buffers): pitch = 32 * ceil(w/32) + 32, so every row segment a block loads or
+// stores is in bounds without a branch; rows outside the image are clamped on load (and zeroed in LDS) and
+// skipped on store.
 //
 // Chunk c (0..N, N = ceil(w/32)) consumes input columns [32c-28, 32c+4) and emits output columns
 // [32c-32, 32c): the input tile is the one that sits 16 bytes off the 128-byte grid, so that the
 // (2.5x larger) output stores are whole aligned 128-byte lines.  Chunk 0 only primes the filter
 // (columns < 0 are the zero padding; its outputs n < 0 do not exist).
-// Wave s loads rows [32*(s&1), +32) of plane (s>>1) (waves 0-3) and stores its own stream's tile.
+// Wave v loads rows [24*(v&1), +24) of plane (v>>1); the 1920 float4 of a chunk's five output tiles are stored
+// by all 256 threads, consecutive threads writing consecutive 16-byte pieces of a row.
 template <int LEVEL>
-__global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *__restrict__ xyb,
-                                                                   const uint32_t *__restrict__ pair_ref,
-                                                                   float *__restrict__ hbuf, uint32_t w, uint32_t h,
-                                                                   uint32_t pitch, size_t plane, uint32_t max_refs,
-                                                                   rg_consts rg, lvl_table tab)
+__global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__restrict__ xyb,
+                                                                const uint32_t *__restrict__ pair_ref,
+                                                                float *__restrict__ hbuf, uint32_t w, uint32_t h,
+                                                                uint32_t pitch, size_t plane, uint32_t max_refs,
+                                                                rg_consts rg, lvl_table tab)
 {
     __shared__ float s_in[2][2 * HB_HALF];  // [plane a|b][half][column][row]
     __shared__ float s_out[CE_SSIM2_STREAMS * HB_HALF];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t s = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform stream index
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t bx = blockIdx.x;
     if (LEVEL < 0) {  // merged launch: which level does this block belong to?
         uint32_t l = 0;
@@ -302,36 +323,45 @@ __global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *
     const float *ga = xyb + ((size_t)pair_ref[p] * 3 + c) * plane;
     const float *gb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane;
     const int n_chunks = (int)(pitch / HB_CW);  // N + 1
-    const uint32_t lr = lane >> 3, lq = lane & 7;  // row-in-group, float4-in-row of this lane's slots
-
-    // load slots m = 0..3: row 32*(s&1) + 8m + lr of plane s>>1, columns 32c-28+4*lq .. +3 of chunk c
-    const bool loader = s < 4;
-    const uint32_t lrow0 = (s & 1) * 32 + lr;
-    const float *src = ((s >> 1) & 1 ? gb : ga) + (size_t)(y0 + lrow0) * pitch;
-    float *sdst = &s_in[(s >> 1) & 1][(4 * lq) * HB_LD + lrow0];
-    // store slots m = 0..7: row 8m + lr of this wave's stream tile, columns 32(c-1)+4*lq .. +3
-    float *odst = hbuf + (((size_t)p * 3 + c) * CE_SSIM2_STREAMS + s) * plane + (size_t)(y0 + lr) * pitch + 4 * lq;
-    const float *osrc = &s_out[s * HB_HALF + (4 * lq) * HB_LD + lr];
-
-    float4 pf[4];  // the next chunk, in flight
+    // Loads and stores are kept in DIFFERENT waves.  vmcnt retires in order, so in a wave that does both a load
+    // issued after a burst of row stores cannot be seen complete before those stores are acknowledged by the memory
+    // side - and under write pressure that takes far longer than the load itself: the chunk loop ran at the pace of
+    // store acknowledgements, whatever the arithmetic cost.  Wave 3 is the only one that loads (768 float4 per
+    // chunk, 12 per lane, one chunk ahead in registers) and never stores; waves 0-2 store (1920 float4 per chunk,
+    // 10 per thread) and never wait on vmcnt.
+    const bool loader = wv == 3;
+    // load slot m = 0..11 of lane: j = 64 m + lane -> plane j / 384, row (j % 384) / 8, float4 (j % 8) of the row
+    uint32_t l_off[12];  // element offset of the slot's row in its plane (row clamped; zeroed in LDS below)
+    uint32_t l_dst[12];  // LDS float index of the slot (within one half)
+    uint32_t l_row[12];
+    const uint32_t lq = lane & 7;
+#pragma unroll
+    for (int m = 0; m < 12; m++) {
+        const uint32_t j = 64 * m + lane, pl = j / (HB_ROWS * 8), row = (j % (HB_ROWS * 8)) >> 3;
+        l_row[m] = y0 + row;
+        l_off[m] = (uint32_t)(pl * 0) + min(y0 + row, h - 1) * pitch;  // plane chosen by pointer below
+        l_dst[m] = pl * (2 * HB_HALF) + (4 * lq) * HB_LD + row;
+    }
+    float4 pf[12];
     auto load_chunk = [&](int k) {
         if (loader) {
             const int col = max(HB_CW * k - 28 + 4 * (int)lq, 0);  // clamped: always a readable address
 #pragma unroll
-            for (int m = 0; m < 4; m++) pf[m] = *reinterpret_cast<const float4 *>(src + (size_t)(8 * m) * pitch + col);
+            for (int m = 0; m < 12; m++) pf[m] = *reinterpret_cast<const float4 *>((m < 6 ? ga : gb) + (size_t)l_off[m] + col);
         }
     };
     auto stash_chunk = [&](int k) {
         if (loader) {
             const int col = HB_CW * k - 28 + 4 * (int)lq;  // outside [0, w) the filter sees zeros
-            float *dst = sdst + (k & 1) * HB_HALF;
+            float *base = &s_in[0][0] + (k & 1) * HB_HALF;
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const bool rv = y0 + lrow0 + 8 * m < h && col >= 0;  // col is a multiple of 4: sign is per float4
-                dst[8 * m] = (rv && col < (int)w) ? pf[m].x : 0.0f;
-                dst[8 * m + HB_LD] = (rv && col + 1 < (int)w) ? pf[m].y : 0.0f;
-                dst[8 * m + 2 * HB_LD] = (rv && col + 2 < (int)w) ? pf[m].z : 0.0f;
-                dst[8 * m + 3 * HB_LD] = (rv && col + 3 < (int)w) ? pf[m].w : 0.0f;
+            for (int m = 0; m < 12; m++) {
+                float *dst = base + l_dst[m];
+                const bool rv = l_row[m] < h && col >= 0;  // col is a multiple of 4: sign is per float4
+                dst[0] = (rv && col < (int)w) ? pf[m].x : 0.0f;
+                dst[HB_LD] = (rv && col + 1 < (int)w) ? pf[m].y : 0.0f;
+                dst[2 * HB_LD] = (rv && col + 2 < (int)w) ? pf[m].z : 0.0f;
+                dst[3 * HB_LD] = (rv && col + 3 < (int)w) ? pf[m].w : 0.0f;
             }
         }
     };
@@ -341,34 +371,40 @@ __global__ __launch_bounds__(HB_THREADS, 3) void k_ssim2_hblur_lds(const float *
     if (n_chunks > 1) load_chunk(1);
     __syncthreads();
 
-    float prev[3] = {0.f, 0.f, 0.f}, prev2[3] = {0.f, 0.f, 0.f}, dp[10], dq[10];
+    // filter task of this thread
+    const bool worker = tid < HB_TASKS;
+    const uint32_t ts = worker ? tid / HB_ROWS : 0, tr = worker ? tid % HB_ROWS : 0;
+    const bool plain = ts < 2;
+    const float *sp = &s_in[(ts == 1 || ts == 3) ? 1 : 0][tr];
+    const float *sq = &s_in[(ts == 2) ? 0 : 1][tr];  // a*a -> a, b*b and a*b -> b (ignored when plain)
+    float *so = &s_out[ts * HB_HALF + tr];
+    hblur_state st;
+    st.p01 = st.q01 = hb_f2{0.0f, 0.0f};
+    st.p2 = st.q2 = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 10; j++) dp[j] = dq[j] = 0.0f;  // inputs before column -28 of chunk 0: zero padding
-    const float *sp = &s_in[(s == 1 || s == 3) ? 1 : 0][lane];
-    const float *sq = &s_in[(s == 2 || s == 0) ? 0 : 1][lane];  // a*a -> a, b*b and a*b -> b (unused when plain)
-    float *so = &s_out[s * HB_HALF + lane];
+    for (int j = 0; j < 10; j++) st.d[j] = 0.0f;  // inputs before column -28 of chunk 0: zero padding
+    float *obase = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane;
 
-    // Iteration k: lay chunk k+1 (requested one iteration ago) into the half nobody reads, request chunk
-    // k+2 into the freed registers, filter chunk k, store its outputs, one barrier.
+    // Iteration k: (wave 3) lay chunk k+1 into the half nobody reads and request chunk k+2; filter chunk k; barrier;
+    // (waves 0-2) store chunk k's outputs; barrier.
     for (int k = 0; k < n_chunks; k++) {
         if (k + 1 < n_chunks) stash_chunk(k + 1);
         if (k + 2 < n_chunks) load_chunk(k + 2);
         const uint32_t oc = (k & 1) * HB_HALF;
-        if (s < 2)
-            hblur_chunk<true>(sp + oc, sq + oc, so, dp, dq, prev, prev2, rg);
-        else
-            hblur_chunk<false>(sp + oc, sq + oc, so, dp, dq, prev, prev2, rg);
-        // the wave stores its own tile (whole 128-byte lines)
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (k > 0) {
+        if (worker) hblur_chunk(sp + oc, sq + oc, plain, so, st, rg);
+        lds_barrier();  // the five output tiles of chunk k are complete; chunk k+1 is complete in LDS
+        if (k > 0 && !loader) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const float4 v = make_float4(osrc[8 * m], osrc[8 * m + HB_LD], osrc[8 * m + 2 * HB_LD], osrc[8 * m + 3 * HB_LD]);
-                *reinterpret_cast<float4 *>(odst + (size_t)(8 * m) * pitch + (size_t)(HB_CW * (k - 1))) = v;
+            for (int it = 0; it < HB_STORES / 192; it++) {
+                const uint32_t idx = it * 192 + tid;
+                const uint32_t os = idx / (HB_ROWS * 8), rem = idx % (HB_ROWS * 8), orow = rem >> 3, oq = rem & 7;
+                const float *src = &s_out[os * HB_HALF + (4 * oq) * HB_LD + orow];
+                const float4 v = make_float4(src[0], src[HB_LD], src[2 * HB_LD], src[3 * HB_LD]);
+                if (y0 + orow < h)
+                    *reinterpret_cast<float4 *>(obase + (size_t)os * plane + (size_t)(y0 + orow) * pitch + HB_CW * (k - 1) + 4 * oq) = v;
             }
         }
-        lds_barrier();  // chunk k+1 is complete in LDS and every wave is done with chunk k's half
+        lds_barrier();  // the output tiles may be overwritten by chunk k+1
     }
 }
 
@@ -779,4 +815,15 @@ int ce_ssim2_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64
     if (mismatches) *mismatches = h[0];
     if (slow_path) *slow_path = h[1];
     return CE_OK;
+}
+
+// debug: resident blocks per CU the runtime computes for the two blur kernels (which: 0 = row pass, 1 = column pass)
+int ce_ssim2_occupancy(int which)
+{
+    int n = -1;
+    if (which == 0)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_ssim2_hblur_lds<0>, HB_THREADS, 0);
+    else
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_ssim2_vblur_dma<0>, 64, 0);
+    return n;
 }

@@ -224,6 +224,8 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg /* [6]
  * (msun cbrtf: two f64 Halley steps) near f32 rounding boundaries.  This runs the f32 bit patterns
  * [first_bits, first_bits + count) through both on the device and reports how many results differ
  * (must be 0) and how many inputs took the fallback. */
+/* resident workgroups per CU that the HIP runtime reports for the SSIMULACRA2 row pass (0) / column pass (1) */
+int ce_debug_ssim2_occupancy(int which);
 int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path);
 
 #ifdef __cplusplus
