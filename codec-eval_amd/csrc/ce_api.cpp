@@ -254,6 +254,8 @@ void ce_batch_destroy(ce_batch *b)
         if (b->ev_prep[l]) hipEventDestroy(b->ev_prep[l]);
         if (b->ev_done[l]) hipEventDestroy(b->ev_done[l]);
     }
+    hipFree(b->d_work_h);
+    hipFree(b->d_work_v);
     hipFree(b->d_partials);
     hipFree(b->d_avg);
     ce_dssim_free(b);
@@ -410,6 +412,7 @@ int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index)
     if (b->h_pair_ref[pair_index] != ref_index || b->pair_ref_dirty) {
         b->h_pair_ref[pair_index] = ref_index;
         b->pair_ref_dirty = true;
+        b->pair_ref_version++;
     }
     return CE_OK;
 }

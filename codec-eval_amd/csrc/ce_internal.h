@@ -75,6 +75,7 @@ struct ce_batch {
     uint32_t *d_pair_ref = nullptr;
     std::vector<uint32_t> h_pair_ref;
     bool pair_ref_dirty = true;
+    uint32_t pair_ref_version = 0;  // bumped whenever the pair -> reference table changes
     // pinned staging ring for host -> device uploads: the host copy into slot k overlaps the DMA of slot k-1
     static constexpr int kStages = 8;  // two per upload worker (ce_eval_batch fills a bucket with 4 host threads)
     uint8_t *h_stage[kStages] = {};
@@ -104,6 +105,9 @@ struct ce_batch {
     ce_dev_scores *d_scores = nullptr;
     ce_dev_scores *h_scores = nullptr;  // pinned
     bool ssim2_ready = false;
+    // XCD-aware work lists of the level-0 row / column pass (ssim2.hip): launch id -> (block, channel, pair)
+    uint2 *d_work_h = nullptr, *d_work_v = nullptr;
+    uint32_t work_len_h = 0, work_len_v = 0, work_cap_h = 0, work_cap_v = 0, work_version = ~0u, work_pairs = 0;
     // reference handles (ce_ref_*): the references' XYB pyramid of the last SSIMULACRA2 run stays valid
     // until a reference is replaced, so later compares only build the distorted side
     bool keep_ref_pyramid = false;

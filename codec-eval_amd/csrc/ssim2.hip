@@ -306,7 +306,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
                                                                 const uint32_t *__restrict__ pair_ref,
                                                                 float *__restrict__ hbuf, uint32_t w, uint32_t h,
                                                                 uint32_t pitch, size_t plane, uint32_t max_refs,
-                                                                rg_consts rg, lvl_table tab)
+                                                                rg_consts rg, lvl_table tab, const uint2 *__restrict__ work)
 {
     __shared__ float s_in[2][2 * HB_HALF];  // [plane a|b][half][column][row]
     __shared__ float s_out[CE_SSIM2_STREAMS * HB_HALF];
@@ -319,7 +319,13 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
         xyb = tab.xyb[l], hbuf = tab.hbuf[l];
         w = tab.w[l], h = tab.h[l], pitch = tab.pitch[l], plane = tab.plane[l];
     }
-    const uint32_t y0 = bx * HB_ROWS, c = blockIdx.y, p = blockIdx.z;
+    uint32_t c = blockIdx.y, p = blockIdx.z;
+    if (LEVEL == 0 && work) {  // XCD-aware 1-D launch: the work list says which (block, channel, pair) this id is
+        const uint2 wi = work[blockIdx.x];
+        if (wi.x == ~0u) return;  // padding entry
+        bx = wi.x & 0xffffu, c = wi.x >> 16, p = wi.y;
+    }
+    const uint32_t y0 = bx * HB_ROWS;
     const float *ga = xyb + ((size_t)pair_ref[p] * 3 + c) * plane;
     const float *gb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane;
     const int n_chunks = (int)(pitch / HB_CW);  // N + 1
@@ -493,7 +499,8 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
                                                         const uint32_t *__restrict__ pair_ref,
                                                         double *__restrict__ partials, uint32_t w, uint32_t h,
                                                         uint32_t pitch, size_t plane, uint32_t max_refs, uint32_t scale,
-                                                        uint32_t max_vblocks, rg_consts rg, lvl_table tab)
+                                                        uint32_t max_vblocks, rg_consts rg, lvl_table tab,
+                                                        const uint2 *__restrict__ work)
 {
     __shared__ __attribute__((aligned(16))) float ring[2 * VB_GROUP];
     uint32_t bx = blockIdx.x;
@@ -505,8 +512,13 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
         w = tab.w[l], h = tab.h[l], pitch = tab.pitch[l], plane = tab.plane[l];
         scale = tab.first_level + l;
     }
+    uint32_t c = blockIdx.y, p = blockIdx.z;
+    if (LEVEL == 0 && work) {  // XCD-aware 1-D launch
+        const uint2 wi = work[blockIdx.x];
+        if (wi.x == ~0u) return;
+        bx = wi.x & 0xffffu, c = wi.x >> 16, p = wi.y;
+    }
     const uint32_t lane = threadIdx.x, x0 = bx * 64;
-    const uint32_t c = blockIdx.y, p = blockIdx.z;
     const bool active = x0 + lane < w;
     const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + x0;
     const float *xa = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + x0;
@@ -707,6 +719,58 @@ int ce_ssim2_prepare(ce_batch *b)
     return CE_OK;
 }
 
+// XCD-aware launch order for the level-0 passes.  Workgroups go to the 8 XCDs round-robin by launch id, and each
+// XCD has its own L2.  The blocks that read the same rows (row pass) or columns (column pass) of one REFERENCE
+// for its different distorted images should therefore carry ids that are congruent mod 8 and close together: the
+// reference's planes are then fetched from HBM once per reference, not once per pair.  The list is built on the
+// host whenever the pair -> reference table changes: keys (reference, channel, block) are dealt to the 8 classes
+// in turn, each key followed by all the pairs of that reference; entry id = slot * 8 + class.
+static int build_one_list(ce_batch *b, uint32_t n_pairs, uint32_t n_blocks, uint2 **d_list, uint32_t *len, uint32_t *cap)
+{
+    ce_ctx *ctx = b->ctx;
+    std::vector<std::vector<uint32_t>> pairs_of(b->max_refs);
+    for (uint32_t p = 0; p < n_pairs; p++) pairs_of[b->h_pair_ref[p]].push_back(p);
+    std::vector<uint2> cls[8];
+    uint32_t k = 0;
+    for (uint32_t r = 0; r < b->max_refs; r++) {
+        if (pairs_of[r].empty()) continue;
+        for (uint32_t c = 0; c < 3; c++)
+            for (uint32_t bx = 0; bx < n_blocks; bx++, k++)
+                for (uint32_t p : pairs_of[r]) cls[k & 7].push_back(make_uint2(bx | (c << 16), p));
+    }
+    size_t longest = 0;
+    for (auto &v : cls) longest = std::max(longest, v.size());
+    std::vector<uint2> flat(longest * 8, make_uint2(~0u, 0u));
+    for (uint32_t x = 0; x < 8; x++)
+        for (size_t sl = 0; sl < cls[x].size(); sl++) flat[sl * 8 + x] = cls[x][sl];
+    if (flat.size() > *cap) {
+        if (*d_list) CE_HIP(ctx, hipFree(*d_list));
+        *d_list = nullptr;
+        CE_HIP(ctx, hipMalloc(d_list, flat.size() * sizeof(uint2)));
+        *cap = (uint32_t)flat.size();
+    }
+    CE_HIP(ctx, hipMemcpyAsync(*d_list, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is pageable and goes out of scope
+    *len = (uint32_t)flat.size();
+    return CE_OK;
+}
+
+static int build_work_lists(ce_batch *b, uint32_t n_pairs, uint32_t hblk, uint32_t vblk)
+{
+    if (b->work_version == b->pair_ref_version && b->work_pairs == n_pairs && b->d_work_h) return CE_OK;
+    if (hblk > 0xffffu || vblk > 0xffffu) {
+        b->ctx->err = "SSIMULACRA2: image too large for the block index of the work list";
+        return CE_ERR_INVALID_ARG;
+    }
+    int rc = build_one_list(b, n_pairs, hblk, &b->d_work_h, &b->work_len_h, &b->work_cap_h);
+    if (rc != CE_OK) return rc;
+    rc = build_one_list(b, n_pairs, vblk, &b->d_work_v, &b->work_len_v, &b->work_cap_v);
+    if (rc != CE_OK) return rc;
+    b->work_version = b->pair_ref_version;
+    b->work_pairs = n_pairs;
+    return CE_OK;
+}
+
 int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs)
 {
     ce_ctx *ctx = b->ctx;
@@ -721,9 +785,9 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                         b->ssim2_ref_levels == std::min(b->n_scales, b->debug_max_scales);
     const uint32_t z0 = cached ? n_refs_used : 0;
     using hblur_fn = void (*)(const float *, const uint32_t *, float *, uint32_t, uint32_t, uint32_t, size_t, uint32_t,
-                              rg_consts, lvl_table);
+                              rg_consts, lvl_table, const uint2 *);
     using vblur_fn = void (*)(const float *, const float *, const uint32_t *, double *, uint32_t, uint32_t, uint32_t,
-                              size_t, uint32_t, uint32_t, uint32_t, rg_consts, lvl_table);
+                              size_t, uint32_t, uint32_t, uint32_t, rg_consts, lvl_table, const uint2 *);
     const hblur_fn h_l0 = k_ssim2_hblur_lds<0>, h_tail = k_ssim2_hblur_lds<-1>;
     const vblur_fn v_l0 = k_ssim2_vblur_dma<0>, v_tail = k_ssim2_vblur_dma<-1>;
     scale_geom g{};
@@ -757,10 +821,13 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                 CE_HIP(ctx, hipEventRecord(b->ev_prep[0], ctx->stream));
                 CE_HIP(ctx, hipStreamWaitEvent(s0, b->ev_prep[0], 0));
             }
-            CE_LAUNCH_ON(ctx, s0, "ssim2_hblur_L0", h_l0, dim3(hblk, 3, n_pairs), dim3(HB_THREADS), 0, b->d_xyb[0], b->d_pair_ref,
-                         b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab);
-            CE_LAUNCH_ON(ctx, s0, "ssim2_vblur_ssim_L0", v_l0, dim3(vblk, 3, n_pairs), dim3(64), 0, b->d_hbuf[0], b->d_xyb[0],
-                         b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab);
+            rc = build_work_lists(b, n_pairs, hblk, vblk);
+            if (rc != CE_OK) return rc;
+            CE_LAUNCH_ON(ctx, s0, "ssim2_hblur_L0", h_l0, dim3(b->work_len_h), dim3(HB_THREADS), 0, b->d_xyb[0], b->d_pair_ref,
+                         b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab, (const uint2 *)b->d_work_h);
+            CE_LAUNCH_ON(ctx, s0, "ssim2_vblur_ssim_L0", v_l0, dim3(b->work_len_v), dim3(64), 0, b->d_hbuf[0], b->d_xyb[0],
+                         b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab,
+                         (const uint2 *)b->d_work_v);
             if (s0 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[0], s0));
         } else {
             const uint32_t l = tab.n++;
@@ -782,10 +849,11 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             CE_HIP(ctx, hipStreamWaitEvent(s1, b->ev_prep[1], 0));
         }
         CE_LAUNCH_ON(ctx, s1, "ssim2_hblur_L1-5", h_tail, dim3(tab.blk_end[tab.n - 1], 3, n_pairs), dim3(HB_THREADS), 0,
-                     (const float *)nullptr, b->d_pair_ref, (float *)nullptr, 0u, 0u, 0u, (size_t)0, b->max_refs, rg, tab);
+                     (const float *)nullptr, b->d_pair_ref, (float *)nullptr, 0u, 0u, 0u, (size_t)0, b->max_refs, rg, tab,
+                     (const uint2 *)nullptr);
         CE_LAUNCH_ON(ctx, s1, "ssim2_vblur_ssim_L1-5", v_tail, dim3(tab_v.blk_end[tab_v.n - 1], 3, n_pairs), dim3(64), 0,
                      (const float *)nullptr, (const float *)nullptr, b->d_pair_ref, b->d_partials, 0u, 0u, 0u, (size_t)0, b->max_refs,
-                     0u, b->max_vblocks, rg, tab_v);
+                     0u, b->max_vblocks, rg, tab_v, (const uint2 *)nullptr);
         if (s1 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[1], s1));
     }
     if (!ctx->prof_serial) {
