@@ -302,10 +302,41 @@ struct upload_job {
     const uint8_t *src;
 };
 
+// true if the runtime knows `p` as page-locked host memory (hipHostMalloc / hipHostRegister): the DMA engine can
+// read it directly
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary pageable pointer is reported as an error: clear it
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
 {
     ce_ctx *ctx = b->ctx;
     if (jobs.empty()) return CE_OK;
+    // Page-locked sources skip the staging ring: one asynchronous copy per image straight from the caller's buffer.
+    // Only ce_eval_batch comes through here, and it collects (synchronises) before it returns, so the buffers
+    // outlive the copies.
+    bool all_pinned = true;
+    for (const auto &j : jobs)
+        if (!is_pinned_host(j.src)) {
+            all_pinned = false;
+            break;
+        }
+    if (all_pinned) {
+        if (b->run_pending) {
+            CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
+            b->run_pending = false;
+        }
+        for (const auto &j : jobs)
+            CE_HIP(ctx, hipMemcpyAsync(j.dst, j.src, b->img_bytes, hipMemcpyHostToDevice, b->up_stream));
+        b->uploads_pending = true;
+        return CE_OK;
+    }
     const int n_threads = (int)std::min<size_t>({(size_t)ce_batch::kStages / 2, jobs.size(),
                                                  (size_t)std::max(1u, std::thread::hardware_concurrency())});
     if (n_threads <= 1 || b->img_bytes < (64u << 10)) {
