@@ -361,13 +361,14 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                                                          uint32_t n_refs_used, uint32_t max_refs)
 {
     constexpr int NP = EPI == EPI_HF ? 2 : 3;
-    constexpr int off = LEN / 2, TW = 64, TR = 32, RAW = TR + LEN - 1;
+    // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
+    constexpr int off = LEN / 2, TW = 64, TR = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
     __shared__ float tile[RAW * TW];
     const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
-    const int c = threadIdx.x & 63, wv = threadIdx.x >> 6, gx = x0 + c, gy0 = y0 + 8 * wv;
-    const bool live = gx < (int)g.w && gy0 < (int)g.h;
-    float res[NP][BW_OUT];
+    const int c = threadIdx.x & 63, wv = threadIdx.x >> 6, gx = x0 + c;
+    const bool col_live = gx < (int)g.w;
+    float res[NP][PARTS][BW_OUT];
 #pragma unroll
     for (int q = 0; q < NP; q++) {
         const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes of this slot
@@ -377,67 +378,76 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
             tile[i] = (Y >= 0 && Y < (int)g.h && X < (int)g.w) ? p[(size_t)Y * g.pitch + X] : 0.0f;
         }
         __syncthreads();
-        if (live) {
-            float v[BW_OUT + LEN - 1];
 #pragma unroll
-            for (int j = 0; j < BW_OUT + LEN - 1; j++) v[j] = tile[(8 * wv + j) * TW + c];
+        for (int part = 0; part < PARTS; part++) {
+            const int ly = 32 * part + 8 * wv, gy0 = y0 + ly;
+            if (col_live && gy0 < (int)g.h) {
+                float v[BW_OUT + LEN - 1];
 #pragma unroll
-            for (int o = 0; o < BW_OUT; o++) {
-                float sum = 0.0f;
+                for (int j = 0; j < BW_OUT + LEN - 1; j++) v[j] = tile[(ly + j) * TW + c];
 #pragma unroll
-                for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
-                res[q][o] = sum * border_scale<LEN>(bk, gy0 + o, (int)g.h, inv_wsum);
+                for (int o = 0; o < BW_OUT; o++) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
+                    res[q][part][o] = sum * border_scale<LEN>(bk, gy0 + o, (int)g.h, inv_wsum);
+                }
             }
         }
     }
-    if (!live) return;
-    float *ps = psy + (size_t)slot * PSY * g.plane + (size_t)gy0 * g.pitch + gx;
+    if (!col_live) return;
     const size_t pl = g.plane;
 #pragma unroll
-    for (int o = 0; o < BW_OUT; o++) {
-        if (gy0 + o >= (int)g.h) break;
-        float *q = ps + (size_t)o * g.pitch;
-        if (EPI == EPI_LF) {
-            const float *xs = xyb + (size_t)slot * 3 * pl + (size_t)(gy0 + o) * g.pitch + gx;
-            const float lx = res[0][o], ly = res[1][o], lb = res[2][o];
-            q[MF0 * pl] = xs[0] - lx;
-            q[MF1 * pl] = xs[pl] - ly;
-            q[MF2 * pl] = xs[2 * pl] - lb;
-            // XybLowFreqToVals
-            const float xmul = 33.832837186260f, ymul = 14.458268100570f, bmul = 49.87984651440f, y_to_b_mul = -0.362267051518f;
-            const float bb = __builtin_fmaf(y_to_b_mul, ly, lb);
-            q[LF2 * pl] = bb * bmul;
-            q[LF0 * pl] = lx * xmul;
-            q[LF1 * pl] = ly * ymul;
-        } else if (EPI == EPI_MF) {
-            const float kRemoveMfRange = 0.29f, kAddMfRange = 0.1f;
-            const float mf0 = res[0][o], mf1 = res[1][o];
-            const float hf0 = q[MF0 * pl] - mf0, hf1 = q[MF1 * pl] - mf1;
-            q[MF0 * pl] = remove_range(kRemoveMfRange, mf0);
-            q[MF1 * pl] = amplify_range(kAddMfRange, mf1);
-            q[MF2 * pl] = res[2][o];
-            // SuppressXByY(hf[1], &hf[0])
-            const float suppress = 46.0f, sv = 0.653020556257f, one_minus_s = 1.0f - 0.653020556257f;
-            const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf1, hf1, suppress), one_minus_s, sv);
-            q[HF0 * pl] = scaler * hf0;
-            q[HF1 * pl] = hf1;
-        } else {
-            const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
-            const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
-            {
-                const float hf = res[0][o];
-                const float uhf = q[HF0 * pl] - hf;
-                q[HF0 * pl] = remove_range(kRemoveHfRange, hf);
-                q[UHF0 * pl] = remove_range(kRemoveUhfRange, uhf);
-            }
-            {
-                float hf = maximum_clamp(res[1][o], kMaxclampHf);
-                float uhf = q[HF1 * pl] - hf;
-                uhf = maximum_clamp(uhf, kMaxclampUhf);
-                uhf *= kMulYUhf;
-                q[UHF1 * pl] = uhf;
-                hf *= kMulYHf;
-                q[HF1 * pl] = amplify_range(kAddHfRange, hf);
+    for (int part = 0; part < PARTS; part++) {
+        const int gy0 = y0 + 32 * part + 8 * wv;
+        if (gy0 >= (int)g.h) break;
+        float *ps = psy + (size_t)slot * PSY * g.plane + (size_t)gy0 * g.pitch + gx;
+#pragma unroll
+        for (int o = 0; o < BW_OUT; o++) {
+            if (gy0 + o >= (int)g.h) break;
+            float *q = ps + (size_t)o * g.pitch;
+            if (EPI == EPI_LF) {
+                const float *xs = xyb + (size_t)slot * 3 * pl + (size_t)(gy0 + o) * g.pitch + gx;
+                const float lx = res[0][part][o], ly = res[1][part][o], lb = res[2][part][o];
+                q[MF0 * pl] = xs[0] - lx;
+                q[MF1 * pl] = xs[pl] - ly;
+                q[MF2 * pl] = xs[2 * pl] - lb;
+                // XybLowFreqToVals
+                const float xmul = 33.832837186260f, ymul = 14.458268100570f, bmul = 49.87984651440f, y_to_b_mul = -0.362267051518f;
+                const float bb = __builtin_fmaf(y_to_b_mul, ly, lb);
+                q[LF2 * pl] = bb * bmul;
+                q[LF0 * pl] = lx * xmul;
+                q[LF1 * pl] = ly * ymul;
+            } else if (EPI == EPI_MF) {
+                const float kRemoveMfRange = 0.29f, kAddMfRange = 0.1f;
+                const float mf0 = res[0][part][o], mf1 = res[1][part][o];
+                const float hf0 = q[MF0 * pl] - mf0, hf1 = q[MF1 * pl] - mf1;
+                q[MF0 * pl] = remove_range(kRemoveMfRange, mf0);
+                q[MF1 * pl] = amplify_range(kAddMfRange, mf1);
+                q[MF2 * pl] = res[2][part][o];
+                // SuppressXByY(hf[1], &hf[0])
+                const float suppress = 46.0f, sv = 0.653020556257f, one_minus_s = 1.0f - 0.653020556257f;
+                const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf1, hf1, suppress), one_minus_s, sv);
+                q[HF0 * pl] = scaler * hf0;
+                q[HF1 * pl] = hf1;
+            } else {
+                const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
+                const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
+                {
+                    const float hf = res[0][part][o];
+                    const float uhf = q[HF0 * pl] - hf;
+                    q[HF0 * pl] = remove_range(kRemoveHfRange, hf);
+                    q[UHF0 * pl] = remove_range(kRemoveUhfRange, uhf);
+                }
+                {
+                    float hf = maximum_clamp(res[1][part][o], kMaxclampHf);
+                    float uhf = q[HF1 * pl] - hf;
+                    uhf = maximum_clamp(uhf, kMaxclampUhf);
+                    uhf *= kMulYUhf;
+                    q[UHF1 * pl] = uhf;
+                    hf *= kMulYHf;
+                    q[HF1 * pl] = amplify_range(kAddHfRange, hf);
+                }
             }
         }
     }
@@ -969,7 +979,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                 return CE_ERR_BACKEND;
             }
             const dim3 gh3((g.w + 255) / 256, (g.h + 7) / 8, n_slots * 3), gh2(gh3.x, gh3.y, n_slots * 2);
-            const dim3 gvs((g.w + 63) / 64, (g.h + 31) / 32, n_slots);
+            const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, n_slots);
             CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1);
             CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy, g,
