@@ -521,24 +521,18 @@ __device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_
     const float scaler2 = mp.norm2_0lt1 / (mp.norm1 + absval);
     const double fabs0 = fabs((double)v0);
     const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
-    if (v0 < 0) {
-        if (v1 > -too_small) {
-            const double impact = scaler2 * (v1 + too_small);
-            r = (float)(r - impact);
-        } else if (v1 < -too_big) {
-            const double impact = scaler2 * (-v1 - too_big);
-            r = (float)(r + impact);
-        }
-    } else {
-        if (v1 < too_small) {
-            const double impact = scaler2 * (too_small - v1);
-            r = (float)(r + impact);
-        } else if (v1 > too_big) {
-            const double impact = scaler2 * (v1 - too_big);
-            r = (float)(r - impact);
-        }
-    }
-    return r;
+    // The four branches of MaltaDiffMap's asymmetry term, without divergence.  Mirror v1 for a negative v0:
+    //   v0 <  0: v1 > -too_small  <=>  u < too_small   impact = scaler2 (v1 + too_small) = scaler2 (too_small - u),  r - impact
+    //            v1 < -too_big    <=>  u > too_big     impact = scaler2 (-v1 - too_big)  = scaler2 (u - too_big),    r + impact
+    //   v0 >= 0: v1 <  too_small  <=>  u < too_small   impact = scaler2 (too_small - v1),                             r + impact
+    //            v1 >  too_big    <=>  u > too_big     impact = scaler2 (v1 - too_big),                               r - impact
+    // with u = v0 < 0 ? -v1 : v1; every value is formed by the same f64 operations as in the branchy form.
+    const bool neg = v0 < 0;
+    const double u = neg ? -(double)v1 : (double)v1;
+    const bool lo = u < too_small, hi = u > too_big;
+    const double impact = (double)scaler2 * (lo ? too_small - u : u - too_big);
+    const double rn = (double)r + ((neg == lo) ? -impact : impact);
+    return (lo || hi) ? (float)rn : r;
 }
 
 // The 16 line sums of MaltaUnit for FOUR horizontally adjacent centres, from a 9 x 12 register window
