@@ -440,10 +440,10 @@ int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index)
     if (!b) return CE_ERR_INVALID_ARG;
     if (pair_index >= b->max_pairs || ref_index >= b->max_refs)
         return fail(b->ctx, CE_ERR_INVALID_ARG, "pair/ref index out of range");
-    if (b->h_pair_ref[pair_index] != ref_index || b->pair_ref_dirty) {
+    if (b->h_pair_ref[pair_index] != ref_index) {
         b->h_pair_ref[pair_index] = ref_index;
         b->pair_ref_dirty = true;
-        b->pair_ref_version++;
+        b->pair_ref_version++;  // device-side tables derived from it (pair_ref, XCD work lists) are rebuilt at the next launch
     }
     return CE_OK;
 }
