@@ -236,12 +236,29 @@ __device__ __forceinline__ void opsin_absorbance(float in0, float in1, float in2
     o2 = __builtin_fmaf(mixi8, in0, __builtin_fmaf(mixi9, in1, __builtin_fmaf(mixi10, in2, mixi11)));
 }
 
+// FastLog2f of the lineage (libjxl lib/jxl/base/fast_math-inl.h): mantissa reduced to [-1/3, 1/3] by integer
+// arithmetic on the bits, (2,2) rational polynomial of log2(1 + t) in Horner form with fused multiply-adds, one
+// IEEE division.  IEEE basic operations only: bit-identical to oracle/butteraugli.c (a libm log2f is not, and on a
+// flat image one ulp of the logarithm moves the score by up to 4e-3 relative).
+__device__ __forceinline__ float fast_log2f(float x)
+{
+    const float p0 = -1.8503833400518310E-06f, p1 = 1.4287160470083755E+00f, p2 = 7.4245873327820566E-01f;
+    const float q0 = 9.9032814277590719E-01f, q1 = 1.0096718572241148E+00f, q2 = 1.7409343003366853E-01f;
+    const int32_t xb = (int32_t)__float_as_uint(x);
+    const int32_t es = (xb - 0x3f2aaaab) >> 23;  // arithmetic shift
+    const float m = __uint_as_float((uint32_t)xb - ((uint32_t)es << 23));
+    const float t = m - 1.0f;
+    const float yp = __builtin_fmaf(__builtin_fmaf(p2, t, p1), t, p0);
+    const float yq = __builtin_fmaf(__builtin_fmaf(q2, t, q1), t, q0);
+    return yp / yq + (float)es;
+}
+
 __device__ __forceinline__ float gamma_f(float v)
 {
     const float kRetMul = 19.245013259874995f * 0.693147180559945f, kRetAdd = -23.16046239805755f;
     if (v < 0.0f) v = 0.0f;
     const float biased = v + 9.9710635769299145f;
-    return __builtin_fmaf(kRetMul, log2f(biased), kRetAdd);
+    return __builtin_fmaf(kRetMul, fast_log2f(biased), kRetAdd);
 }
 
 // Front end, fused: linear RGB tile (level 0: sRGB u8 through the table; level 1: the subsampled planes) with a
