@@ -34,3 +34,27 @@ def test_random_shapes_and_contents_all_metrics(gpu_ctx, oracle, ce, workloads):
     # far inside the 1e-4 bar: SSIMULACRA2 differs only through f32 pooling of the map terms, DSSIM and Butteraugli
     # follow the oracle's operations one for one
     assert worst["ssimulacra2"] < 1e-6 and worst["dssim"] < 1e-9 and worst["butteraugli"] < 1e-6, worst
+
+
+def test_irregular_pair_to_reference_bindings(gpu_ctx, ce, workloads):
+    """The level-0 SSIMULACRA2 passes run from host-built XCD-aware work lists keyed by the pair -> reference table.
+    Unsorted pairs, references with 0, 1 or many pairs, re-binding between runs: every pair must score exactly what
+    it scores alone."""
+    rng = np.random.default_rng(5)
+    w, h, R, P = 150, 110, 7, 23
+    cfg = ce.MetricConfig(ssimulacra2=True, psnr=True)
+    refs = [workloads.make_reference(w, h, 100 + i) for i in range(R)]
+    b = ce.Batch(gpu_ctx, w, h, R, P)
+    for i, r in enumerate(refs):
+        b.set_reference(i, r)
+    for rnd in range(3):
+        bind = rng.integers(0, R if rnd else 3, P)  # round 0: only references 0..2 are used
+        tests = [workloads.distort(refs[int(bind[k])], int(rng.integers(20, 98))) for k in range(P)]
+        for k in range(P):
+            b.set_test(k, int(bind[k]), tests[k])
+        n = P if rnd != 1 else 11  # a shorter run in between
+        out = b.run(n, cfg)
+        for k in range(n):
+            solo = gpu_ctx.calculate_metrics(refs[int(bind[k])], tests[k], w, h, cfg)
+            assert (out[k].ssimulacra2, out[k].psnr) == (solo.ssimulacra2, solo.psnr), (rnd, k, int(bind[k]))
+    b.close()
