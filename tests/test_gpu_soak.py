@@ -58,3 +58,36 @@ def test_irregular_pair_to_reference_bindings(gpu_ctx, ce, workloads):
             solo = gpu_ctx.calculate_metrics(refs[int(bind[k])], tests[k], w, h, cfg)
             assert (out[k].ssimulacra2, out[k].psnr) == (solo.ssimulacra2, solo.psnr), (rnd, k, int(bind[k]))
     b.close()
+
+
+def test_contexts_on_concurrent_host_threads(oracle, ce, workloads):
+    """SURVEY.md 8b threading: one in-flight call per context, any number of contexts per device, created and used from
+    different host threads (full_comparison.rs:319-328 calls the leaf functions from rayon workers)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    w, h = 120, 90
+    cases = []
+    for i in range(6):
+        ref = workloads.make_reference(w, h, 900 + i)
+        test = workloads.distort(ref, 40 + 9 * i)
+        cases.append((ref, test, oracle.ssimulacra2(ref, test, w, h, 1), oracle.psnr(ref, test, w, h)))
+
+    def worker(idx):
+        ctx = ce.Context(0)
+        out = []
+        for rep in range(8):
+            ref, test, _, _ = cases[(idx + rep) % len(cases)]
+            m = ctx.calculate_metrics(ref, test, w, h, ce.MetricConfig(ssimulacra2=True, psnr=True, dssim=True, butteraugli=True))
+            out.append(((idx + rep) % len(cases), m))
+        ctx.close()
+        return out
+
+    with ThreadPoolExecutor(4) as ex:
+        results = list(ex.map(worker, range(4)))
+    first = {}
+    for res in results:
+        for k, m in res:
+            _, _, s2, ps = cases[k]
+            assert m.psnr == ps and abs(m.ssimulacra2 - s2) <= 1e-4 * max(abs(s2), 1.0)
+            key = (m.ssimulacra2, m.dssim, m.butteraugli)
+            assert first.setdefault(k, key) == key  # every thread / context gets the same bits
