@@ -593,9 +593,9 @@ int ce_batch_run(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t f
 
 // ---- single pair / mixed batch ----------------------------------------------------------------
 
-static int shape_batch(ce_ctx *ctx, uint32_t w, uint32_t h, uint32_t need_pairs, ce_batch **out)
+static int shape_batch(ce_ctx *ctx, uint32_t w, uint32_t h, uint32_t need_pairs, uint32_t ring_slot, ce_batch **out)
 {
-    auto key = std::make_pair(w, h);
+    auto key = std::make_tuple(w, h, ring_slot);
     auto it = ctx->shape_pool.find(key);
     if (it != ctx->shape_pool.end() && it->second->max_pairs >= need_pairs) {
         *out = it->second;
@@ -631,47 +631,82 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
         }
         buckets[{d.width, d.height}].push_back(i);
     }
-    // Phase 1: fill and launch every shape bucket (uploads of one bucket overlap the kernels of the previous one);
-    // phase 2: collect.
-    std::vector<ce_batch *> launched;
+    // Phase 1: fill and launch.  A bucket is streamed through up to kPoolRing pooled batches in chunks of whole
+    // references (all pairs of a reference stay together, identical reference pointers share one device slot): the
+    // uploads of a chunk run on that batch's upload stream and overlap the kernels of the chunk before it.
+    // Phase 2: collect, in launch order.
+    struct chunk {
+        ce_batch *b;
+        std::vector<size_t> items;  // indices into pairs[] / out[]
+    };
+    std::vector<chunk> chunks;
+    uint32_t ring = 0;
     for (auto &kv : buckets) {
         const std::vector<size_t> &idx = kv.second;
-        ce_batch *b = nullptr;
-        int rc = shape_batch(ctx, kv.first.first, kv.first.second, (uint32_t)idx.size(), &b);
-        if (rc != CE_OK) return rc;
-        // identical reference pointers share one device slot (the quality sweep of one source image)
-        std::map<const uint8_t *, uint32_t> ref_slot;
-        std::vector<upload_job> jobs;
-        for (size_t k = 0; k < idx.size(); k++) {
-            const ce_pair_desc &d = pairs[idx[k]];  // lengths were validated above against this bucket's shape
-            auto it = ref_slot.find(d.reference);
-            uint32_t slot;
-            if (it == ref_slot.end()) {
-                slot = (uint32_t)ref_slot.size();
-                ref_slot[d.reference] = slot;
-                jobs.push_back({b->d_refs + (size_t)slot * b->img_bytes, d.reference});
+        // group the bucket's items by reference pointer, first-appearance order
+        std::map<const uint8_t *, size_t> group_of;
+        std::vector<std::vector<size_t>> groups;
+        for (size_t i : idx) {
+            auto it = group_of.find(pairs[i].reference);
+            if (it == group_of.end()) {
+                group_of[pairs[i].reference] = groups.size();
+                groups.emplace_back();
+                groups.back().push_back(i);
             } else {
-                slot = it->second;
+                groups[it->second].push_back(i);
             }
-            rc = ce_batch_bind_pair(b, (uint32_t)k, slot);
-            if (rc != CE_OK) return rc;
-            jobs.push_back({b->d_tests + (size_t)k * b->img_bytes, d.test});
         }
-        b->ssim2_ref_src = nullptr;
-        b->refs_rt_valid = false;
-        rc = upload_many(b, jobs);
-        if (rc != CE_OK) return rc;
-        rc = ce_batch_launch(b, (uint32_t)idx.size(), metric_mask, flags, intensity_target);
-        if (rc != CE_OK) return rc;
-        launched.push_back(b);
+        const size_t n_chunks = std::min<size_t>(ce_ctx::kPoolRing, std::max<size_t>(1, idx.size() / 16));
+        const size_t target = (idx.size() + n_chunks - 1) / n_chunks;
+        size_t g0 = 0;
+        while (g0 < groups.size()) {
+            size_t g1 = g0, count = 0;
+            while (g1 < groups.size() && (count == 0 || count + groups[g1].size() <= target)) count += groups[g1++].size();
+            // a ring slot may still be in flight from an earlier chunk of this call: collect it first
+            const uint32_t slot = ring++ % ce_ctx::kPoolRing;
+            for (auto &c : chunks)
+                if (c.b && std::get<2>(c.b->pool_key) == slot && std::get<0>(c.b->pool_key) == kv.first.first &&
+                    std::get<1>(c.b->pool_key) == kv.first.second && !c.items.empty() && c.b->run_pending) {
+                    std::vector<ce_scores> tmp(c.items.size());
+                    int rc = ce_batch_collect(c.b, (uint32_t)c.items.size(), tmp.data());
+                    if (rc != CE_OK) return rc;
+                    for (size_t k = 0; k < c.items.size(); k++) out[c.items[k]] = tmp[k];
+                    c.b = nullptr;  // collected
+                }
+            ce_batch *b = nullptr;
+            int rc = shape_batch(ctx, kv.first.first, kv.first.second, (uint32_t)count, slot, &b);
+            if (rc != CE_OK) return rc;
+            b->pool_key = std::make_tuple(kv.first.first, kv.first.second, slot);
+            chunk ch{b, {}};
+            std::vector<upload_job> jobs;
+            uint32_t k = 0;
+            for (size_t g = g0; g < g1; g++) {
+                const uint32_t ref_slot = (uint32_t)(g - g0);
+                jobs.push_back({b->d_refs + (size_t)ref_slot * b->img_bytes, pairs[groups[g][0]].reference});
+                for (size_t i : groups[g]) {
+                    rc = ce_batch_bind_pair(b, k, ref_slot);
+                    if (rc != CE_OK) return rc;
+                    jobs.push_back({b->d_tests + (size_t)k * b->img_bytes, pairs[i].test});
+                    ch.items.push_back(i);
+                    k++;
+                }
+            }
+            b->ssim2_ref_src = nullptr;
+            b->refs_rt_valid = false;
+            rc = upload_many(b, jobs);
+            if (rc != CE_OK) return rc;
+            rc = ce_batch_launch(b, k, metric_mask, flags, intensity_target);
+            if (rc != CE_OK) return rc;
+            chunks.push_back(std::move(ch));
+            g0 = g1;
+        }
     }
-    size_t bi = 0;
-    for (auto &kv : buckets) {
-        const std::vector<size_t> &idx = kv.second;
-        std::vector<ce_scores> tmp(idx.size());
-        int rc = ce_batch_collect(launched[bi++], (uint32_t)idx.size(), tmp.data());
+    for (auto &c : chunks) {
+        if (!c.b) continue;  // already collected when its ring slot was reused
+        std::vector<ce_scores> tmp(c.items.size());
+        int rc = ce_batch_collect(c.b, (uint32_t)c.items.size(), tmp.data());
         if (rc != CE_OK) return rc;
-        for (size_t k = 0; k < idx.size(); k++) out[idx[k]] = tmp[k];
+        for (size_t k = 0; k < c.items.size(); k++) out[c.items[k]] = tmp[k];
     }
     return CE_OK;
 }

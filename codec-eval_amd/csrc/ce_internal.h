@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -61,7 +62,10 @@ struct ce_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
 
     // scratch batches for the single-pair / mixed-shape entry points, keyed by shape
-    std::map<std::pair<uint32_t, uint32_t>, ce_batch *> shape_pool;
+    // scratch pool for the host-buffer entry points: up to kPoolRing batches per shape (ce_eval_batch streams a large
+    // bucket through them in chunks so that the upload of one chunk overlaps the kernels of the previous one)
+    static constexpr uint32_t kPoolRing = 3;
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ce_batch *> shape_pool;
 };
 
 struct ce_batch {
@@ -75,6 +79,7 @@ struct ce_batch {
     uint32_t *d_pair_ref = nullptr;
     std::vector<uint32_t> h_pair_ref;
     bool pair_ref_dirty = true;
+    std::tuple<uint32_t, uint32_t, uint32_t> pool_key{0, 0, 0};  // (w, h, ring slot) when owned by a context's scratch pool
     uint32_t pair_ref_version = 0;  // bumped whenever the pair -> reference table changes
     // pinned staging ring for host -> device uploads: the host copy into slot k overlaps the DMA of slot k-1
     static constexpr int kStages = 8;  // two per upload worker (ce_eval_batch fills a bucket with 4 host threads)

@@ -91,3 +91,25 @@ def test_contexts_on_concurrent_host_threads(oracle, ce, workloads):
             assert m.psnr == ps and abs(m.ssimulacra2 - s2) <= 1e-4 * max(abs(s2), 1.0)
             key = (m.ssimulacra2, m.dssim, m.butteraugli)
             assert first.setdefault(k, key) == key  # every thread / context gets the same bits
+
+
+def test_eval_batch_streams_large_buckets_in_chunks(gpu_ctx, ce, workloads):
+    """ce_eval_batch streams a bucket of more than ~16 pairs through a ring of pooled batches in chunks of whole
+    references (uploads of a chunk overlap the previous chunk's kernels).  Scores must come back in the caller's
+    order whatever the interleaving of references and shapes, and repeated calls must reuse the pool correctly."""
+    rng = np.random.default_rng(11)
+    shapes = [(96, 64), (64, 96)]
+    refs = {s: [workloads.make_reference(s[0], s[1], 50 + 10 * si + i) for i in range(7)] for si, s in enumerate(shapes)}
+    cfg = ce.MetricConfig(ssimulacra2=True, psnr=True)
+    for rnd in range(2):
+        pairs = []
+        for _ in range(75):
+            s = shapes[int(rng.integers(0, 2))]
+            r = refs[s][int(rng.integers(0, 7))]
+            pairs.append((r, workloads.distort(r, int(rng.integers(10, 99))), s[0], s[1]))
+        out = gpu_ctx.eval_batch(pairs, cfg)
+        assert len(out) == len(pairs) and all(o.status == 0 for o in out)
+        for k in rng.choice(len(pairs), 12, replace=False):
+            r, t, w, h = pairs[int(k)]
+            solo = gpu_ctx.calculate_metrics(r, t, w, h, cfg)
+            assert (out[int(k)].ssimulacra2, out[int(k)].psnr) == (solo.ssimulacra2, solo.psnr), (rnd, int(k))
