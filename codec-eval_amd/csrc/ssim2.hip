@@ -228,7 +228,13 @@ __device__ __forceinline__ void lds_barrier()
 // registers ahead of the filter, then laid into LDS column-major ([column][row], row stride 49 -> per-lane row
 // access without bank conflicts inside a stream).  The LDS input tile holds two 32-column halves (double buffer);
 // outputs leave through a second LDS tile as coalesced 16-byte row stores of whole 128-byte lines.
-constexpr int HB_ROWS = 48, HB_CW = 32, HB_LD = HB_ROWS + 1, HB_THREADS = 256;
+#ifndef CE_HB_ROWS
+#define CE_HB_ROWS 48
+#endif
+constexpr int HB_ROWS = CE_HB_ROWS, HB_CW = 32, HB_LD = HB_ROWS + 1, HB_THREADS = 256;
+constexpr int HB_LOADS = 2 * HB_ROWS * 8;                    // float4 loads per chunk (two planes)
+constexpr int HB_LSLOTS = (HB_LOADS + 63) / 64;             // load slots per lane of the loader wave
+static_assert(HB_ROWS * CE_SSIM2_STREAMS <= HB_THREADS, "one task per thread");
 constexpr int HB_HALF = HB_CW * HB_LD;
 constexpr int HB_TASKS = HB_ROWS * CE_SSIM2_STREAMS;  // 240 (stream, row) lanes
 constexpr int HB_STORES = CE_SSIM2_STREAMS * HB_ROWS * (HB_CW / 4);  // float4 stores per chunk: 1920
@@ -337,23 +343,23 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
     // 10 per thread) and never wait on vmcnt.
     const bool loader = wv == 3;
     // load slot m = 0..11 of lane: j = 64 m + lane -> plane j / 384, row (j % 384) / 8, float4 (j % 8) of the row
-    uint32_t l_off[12];  // element offset of the slot's row in its plane (row clamped; zeroed in LDS below)
-    uint32_t l_dst[12];  // LDS float index of the slot (within one half)
-    uint32_t l_row[12];
+    const float *l_src[HB_LSLOTS];  // the slot's row in its plane (row clamped; zeroed in LDS below)
+    uint32_t l_dst[HB_LSLOTS];      // LDS float index of the slot (within one half)
+    uint32_t l_row[HB_LSLOTS];      // image row of the slot; ~0 for a slot past the end of the list
     const uint32_t lq = lane & 7;
 #pragma unroll
-    for (int m = 0; m < 12; m++) {
-        const uint32_t j = 64 * m + lane, pl = j / (HB_ROWS * 8), row = (j % (HB_ROWS * 8)) >> 3;
-        l_row[m] = y0 + row;
-        l_off[m] = (uint32_t)(pl * 0) + min(y0 + row, h - 1) * pitch;  // plane chosen by pointer below
+    for (int m = 0; m < HB_LSLOTS; m++) {
+        const uint32_t j = min(64u * m + lane, (uint32_t)HB_LOADS - 1), pl = j / (HB_ROWS * 8), row = (j % (HB_ROWS * 8)) >> 3;
+        l_row[m] = 64u * m + lane < (uint32_t)HB_LOADS ? y0 + row : ~0u;
+        l_src[m] = (pl ? gb : ga) + (size_t)min(y0 + row, h - 1) * pitch;
         l_dst[m] = pl * (2 * HB_HALF) + (4 * lq) * HB_LD + row;
     }
-    float4 pf[12];
+    float4 pf[HB_LSLOTS];
     auto load_chunk = [&](int k) {
         if (loader) {
             const int col = max(HB_CW * k - 28 + 4 * (int)lq, 0);  // clamped: always a readable address
 #pragma unroll
-            for (int m = 0; m < 12; m++) pf[m] = *reinterpret_cast<const float4 *>((m < 6 ? ga : gb) + (size_t)l_off[m] + col);
+            for (int m = 0; m < HB_LSLOTS; m++) pf[m] = *reinterpret_cast<const float4 *>(l_src[m] + col);
         }
     };
     auto stash_chunk = [&](int k) {
@@ -361,7 +367,8 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
             const int col = HB_CW * k - 28 + 4 * (int)lq;  // outside [0, w) the filter sees zeros
             float *base = &s_in[0][0] + (k & 1) * HB_HALF;
 #pragma unroll
-            for (int m = 0; m < 12; m++) {
+            for (int m = 0; m < HB_LSLOTS; m++) {
+                if (l_row[m] == ~0u) continue;  // past the end of the slot list (only when 2*HB_ROWS*8 is not a multiple of 64)
                 float *dst = base + l_dst[m];
                 const bool rv = l_row[m] < h && col >= 0;  // col is a multiple of 4: sign is per float4
                 dst[0] = (rv && col < (int)w) ? pf[m].x : 0.0f;
@@ -401,8 +408,9 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
         lds_barrier();  // the five output tiles of chunk k are complete; chunk k+1 is complete in LDS
         if (k > 0 && !loader) {
 #pragma unroll
-            for (int it = 0; it < HB_STORES / 192; it++) {
+            for (int it = 0; it < (HB_STORES + 191) / 192; it++) {
                 const uint32_t idx = it * 192 + tid;
+                if (idx >= (uint32_t)HB_STORES) break;
                 const uint32_t os = idx / (HB_ROWS * 8), rem = idx % (HB_ROWS * 8), orow = rem >> 3, oq = rem & 7;
                 const float *src = &s_out[os * HB_HALF + (4 * oq) * HB_LD + orow];
                 const float4 v = make_float4(src[0], src[HB_LD], src[2 * HB_LD], src[3 * HB_LD]);
