@@ -361,26 +361,31 @@ struct ds_geom {
     uint32_t nblk[CE_DSSIM_SCALES];
 };
 
-__global__ void k_dssim_finalize_pairs(const double *__restrict__ part, double *__restrict__ level_scores,
-                                       ce_dev_scores *__restrict__ scores, uint32_t n_pairs, uint32_t n_levels,
-                                       uint32_t n_blocks, ds_geom g)
+// one wave per pair: the per-block deviation sums of every level are added lane-strided and then across the wave
+// (a fixed order, so the result is reproducible), lane 0 forms the level scores and the final value
+__global__ __launch_bounds__(64) void k_dssim_finalize_pairs(const double *__restrict__ part, double *__restrict__ level_scores,
+                                                             ce_dev_scores *__restrict__ scores, uint32_t n_pairs,
+                                                             uint32_t n_levels, uint32_t n_blocks, ds_geom g)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = blockIdx.x, lane = threadIdx.x;
     if (p >= n_pairs) return;
     const double W[CE_DSSIM_SCALES] = {0.028, 0.197, 0.322, 0.298, 0.155};
     double ssim_sum = 0.0, weight_sum = 0.0;
     for (uint32_t l = 0; l < n_levels; l++) {
         const double *pp = part + (((size_t)p * n_levels + l) * 2 + 1) * n_blocks;
         double dev = 0.0;
-        for (uint32_t k = 0; k < g.nblk[l]; k++) dev += pp[k];
+        for (uint32_t k = lane; k < g.nblk[l]; k += 64) dev += pp[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dev += __shfl_down(dev, off, 64);
+        dev = __shfl(dev, 0, 64);
         const double score = 1.0 - dev / (double)g.npix[l];
-        level_scores[(size_t)p * CE_DSSIM_SCALES + l] = score;
+        if (lane == 0) level_scores[(size_t)p * CE_DSSIM_SCALES + l] = score;
         ssim_sum += score * W[l];
         weight_sum += W[l];
     }
     double ssim = ssim_sum / weight_sum;
     if (!(ssim > 2.220446049250313e-16)) ssim = 2.220446049250313e-16;
-    scores[p].dssim = 1.0 / ssim - 1.0;
+    if (lane == 0) scores[p].dssim = 1.0 / ssim - 1.0;
 }
 
 }  // namespace
@@ -465,7 +470,7 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         g.npix[l] = d.w * d.h;
         g.nblk[l] = gp.x * gp.y;
     }
-    CE_LAUNCH(ctx, "dssim_finalize", k_dssim_finalize_pairs, dim3((n_pairs + 63) / 64), dim3(64), 0, b->ds_part,
+    CE_LAUNCH(ctx, "dssim_finalize", k_dssim_finalize_pairs, dim3(n_pairs), dim3(64), 0, b->ds_part,
               b->ds_level_scores, b->d_scores, n_pairs, (uint32_t)b->ds_levels, b->ds_blocks, g);
     CE_HIP(ctx, hipGetLastError());
     return CE_OK;
