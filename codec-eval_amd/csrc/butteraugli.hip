@@ -573,7 +573,7 @@ __device__ __forceinline__ void malta_unit4(const float (&win)[9][12], float (&a
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_ba_malta_l2(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+__global__ __launch_bounds__(TPB, 4) void k_ba_malta_l2(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
                                                      float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
                                                      uint32_t n_pairs_stride, malta_bands mb)
 {
