@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # SURVEY.md §8(d) algorithmic bytes, counting rules R1-R6
 SSIM2_BYTES_PER_PX0_TOTAL = 210.0  # whole metric, per scale-0 pixel of a pair
+# the other leaves, counted with the same rules from the oracle's stage lists (BASELINE.md §4 has the sums)
+METRIC_BYTES_PER_PX0 = {"ssimulacra2": SSIM2_BYTES_PER_PX0_TOTAL, "dssim": 238.0, "butteraugli": 826.0, "psnr": 6.0}
 SSIM2_PASS_BYTES_L0 = 66.0  # one blur pass at level 0: 60 B of blurred planes + 6 B of u8 input
 
 
@@ -223,9 +225,19 @@ def main():
                 n0, ms0 = solo.get(k, (0, 0.0))
                 solo[k] = (n0 + n, ms0 + ms)
             c.prof_enable(False)
-    if rank == 0 and kernels:
+    px0 = sum(len(g.pairs) * g.width * g.height for g in grids)  # scale-0 pixels per step
+    step_bytes = px0 * (sum(b for m, b in METRIC_BYTES_PER_PX0.items() if getattr(cfg, m)) + (6.0 if cfg.xyb_roundtrip else 0.0))
+    if rank == 0 and args.config != 2:
+        # the other configs run several metrics' kernel chains side by side: quote the whole step against the HBM peak
+        roofline = {
+            "bound": "hbm", "kernel": None, "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_step": step_bytes,
+            "note": "whole step (all enabled metrics, uncached-pair byte counts of BASELINE.md §4) over the timed step; "
+                    "per-kernel rooflines are quoted on the headline config only",
+        }
+    elif rank == 0 and kernels:
         total_ms = sum(ms for _, ms in kernels.values())
-        px0 = sum(len(g.pairs) * g.width * g.height for g in grids)  # scale-0 pixels per step
 
         def tail_pixels(w, h):  # pyramid levels 1..5 (ceil halving; a level exists while both sides are >= 8)
             n, lv = 0, 1
