@@ -517,7 +517,7 @@ __device__ constexpr mline MALTA_LF[16] = {
     {5, {{2, -4}, {1, -2}, {0, 0}, {-1, 2}, {-2, 4}}},
 };
 
-constexpr int MT = 32, MH = 4, ML = MT + 2 * MH;  // 32x32 outputs per block from a zero-padded 40x40 LDS tile
+constexpr int MT = 64, MH = 4, ML = MT + 2 * MH;  // 64x64 outputs per block from a zero-padded 72x72 LDS tile (1.27x halo)
 
 // ---- per pair, fused: the three Malta bands of one channel + that channel's L2 terms -----------------------------
 // For channel c in {X, Y}: UHF (9-sample lines), HF and MF (5-sample lines).  Per band the two images' 40x40
@@ -578,19 +578,19 @@ __global__ __launch_bounds__(TPB, 4) void k_ba_malta_l2(const float *__restrict_
                                                      uint32_t n_pairs_stride, malta_bands mb)
 {
     __shared__ __attribute__((aligned(16))) float s[ML * ML];
+    __shared__ __attribute__((aligned(16))) float s_acc[MT * MT];  // the block's running sums; each thread owns its entries
     const uint32_t p = blockIdx.z / 3, c = blockIdx.z % 3;
     const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MT - MH;
     const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane;
     const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane;
-    // thread -> four adjacent outputs: columns 4*tq .. 4*tq+3 of tile row ty
+    // thread -> four adjacent outputs (columns 4*tq .. 4*tq+3 of row ty) in each of the tile's four 32x32 quadrants
     const int tq = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < 2) {
-        const uint32_t band_plane[3] = {UHF0 + c, HF0 + c, MF0 + c};
 #pragma unroll
         for (int band = 0; band < 3; band++) {
             const malta_params mp = mb.p[c][band];
-            const float *pa = a + (size_t)band_plane[band] * g.plane, *pb = b + (size_t)band_plane[band] * g.plane;
+            const uint32_t band_plane = (band == 0 ? UHF0 : band == 1 ? HF0 : MF0) + c;
+            const float *pa = a + (size_t)band_plane * g.plane, *pb = b + (size_t)band_plane * g.plane;
             for (int i = threadIdx.x; i < ML * ML; i += TPB) {
                 const int lx = i % ML, ly = i / ML, gx = x0 + lx, gy = y0 + ly;
                 float v = 0.0f;
@@ -601,35 +601,45 @@ __global__ __launch_bounds__(TPB, 4) void k_ba_malta_l2(const float *__restrict_
                 s[i] = v;
             }
             __syncthreads();
-            float win[9][12];
+#pragma unroll 1
+            for (int sub = 0; sub < 4; sub++) {
+                float4 *pacc = reinterpret_cast<float4 *>(s_acc + (32 * (sub >> 1) + ty) * MT + 32 * (sub & 1) + 4 * tq);
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};  // this band's sums; 0 + ret is exact, so adding them afterwards is the same sum
+                float win[9][12];
 #pragma unroll
-            for (int r = 0; r < 9; r++) {
-                const float4 *row = reinterpret_cast<const float4 *>(s + (ty + r) * ML + 4 * tq);
+                for (int r = 0; r < 9; r++) {
+                    const float4 *row = reinterpret_cast<const float4 *>(s + (32 * (sub >> 1) + ty + r) * ML + 32 * (sub & 1) + 4 * tq);
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const float4 v = row[q];
-                    win[r][4 * q] = v.x;
-                    win[r][4 * q + 1] = v.y;
-                    win[r][4 * q + 2] = v.z;
-                    win[r][4 * q + 3] = v.w;
+                    for (int q = 0; q < 3; q++) {
+                        const float4 v = row[q];
+                        win[r][4 * q] = v.x;
+                        win[r][4 * q + 1] = v.y;
+                        win[r][4 * q + 2] = v.z;
+                        win[r][4 * q + 3] = v.w;
+                    }
                 }
+                // block_diff_ac accumulates band by band in the lineage: same order here
+                if (band == 0)
+                    malta_unit4<false>(win, acc);
+                else
+                    malta_unit4<true>(win, acc);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (band != 0) t = *pacc;
+                *pacc = make_float4(t.x + acc[0], t.y + acc[1], t.z + acc[2], t.w + acc[3]);
             }
-            // block_diff_ac accumulates band by band in the lineage: same order here
-            if (band == 0)
-                malta_unit4<false>(win, acc);
-            else
-                malta_unit4<true>(win, acc);
             __syncthreads();
         }
     }
     const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
     const float hf_asymmetry = 1.0f;
+#pragma unroll 1
+    for (int sub = 0; sub < 4; sub++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const uint32_t x = blockIdx.x * MT + 4 * tq + r, y = blockIdx.y * MT + ty;
+        const uint32_t x = blockIdx.x * MT + 32 * (sub & 1) + 4 * tq + r, y = blockIdx.y * MT + 32 * (sub >> 1) + ty;
         if (x >= g.w || y >= g.h) continue;
         const size_t o = (size_t)y * g.pitch + x;
-        float total = acc[r];
+        float total = c < 2 ? s_acc[(32 * (sub >> 1) + ty) * MT + 32 * (sub & 1) + 4 * tq + r] : 0.0f;
         if (c < 2) {  // L2DiffAsymmetric on hf[c]
             const float vw_0gt1 = wmul[c] * hf_asymmetry * 0.8f, vw_0lt1 = wmul[c] / hf_asymmetry * 0.8f;
             const float val0 = a[(HF0 + c) * g.plane + o], val1 = b[(HF0 + c) * g.plane + o];
