@@ -207,7 +207,8 @@ int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_r
     // +16 bytes: the PSNR kernel reads whole 16-byte words
     chk(hipMalloc(&b->d_refs, b->img_bytes * max_refs + 16), "hipMalloc refs");
     chk(hipMalloc(&b->d_tests, b->img_bytes * max_pairs + 16), "hipMalloc tests");
-    chk(hipMalloc(&b->d_pair_ref, sizeof(uint32_t) * max_pairs), "hipMalloc pair_ref");
+    chk(hipMalloc(&b->d_pair_ref, sizeof(uint32_t) * 2 * max_pairs), "hipMalloc pair_ref");  // [pair_ref | pair_first]
+    b->d_pair_first = b->d_pair_ref ? b->d_pair_ref + max_pairs : nullptr;
     chk(hipMalloc(&b->d_scores, sizeof(ce_dev_scores) * max_pairs), "hipMalloc scores");
     chk(hipHostMalloc(&b->h_scores, sizeof(ce_dev_scores) * max_pairs, hipHostMallocDefault), "hipHostMalloc scores");
     chk(hipStreamCreateWithFlags(&b->up_stream, hipStreamNonBlocking), "hipStreamCreate upload");
@@ -256,6 +257,8 @@ void ce_batch_destroy(ce_batch *b)
     }
     hipFree(b->d_work_h);
     hipFree(b->d_work_v);
+    hipFree(b->d_work_ht);
+    hipFree(b->d_work_vt);
     hipFree(b->d_partials);
     hipFree(b->d_avg);
     ce_dssim_free(b);
@@ -489,9 +492,17 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         if (rc != CE_OK) return rc;
     }
     if (b->pair_ref_dirty) {
-        CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, b->h_pair_ref.data(), sizeof(uint32_t) * b->max_pairs,
-                                   hipMemcpyHostToDevice, ctx->stream));
-        CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h_pair_ref is pageable
+        // pair_first[p] = the lowest pair index bound to the same reference as p: that pair's row pass also produces
+        // the two reference-only blur streams (a, a*a) which every pair of the reference then reads (ssim2.hip)
+        std::vector<uint32_t> table(2 * (size_t)b->max_pairs), first_of(b->max_refs, ~0u);
+        for (uint32_t i = 0; i < b->max_pairs; i++) {
+            const uint32_t r = b->h_pair_ref[i];
+            if (first_of[r] == ~0u) first_of[r] = i;
+            table[i] = r;
+            table[b->max_pairs + i] = first_of[r];
+        }
+        CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, table.data(), sizeof(uint32_t) * table.size(), hipMemcpyHostToDevice, ctx->stream));
+        CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable
         b->pair_ref_dirty = false;
     }
     uint32_t n_refs_used = 0;

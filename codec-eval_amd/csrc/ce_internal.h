@@ -77,6 +77,7 @@ struct ce_batch {
     uint8_t *d_refs_rt = nullptr;  // XYB-roundtripped references (lazily allocated)
     uint8_t *d_tests = nullptr;    // [max_pairs][h][w][3]
     uint32_t *d_pair_ref = nullptr;
+    uint32_t *d_pair_first = nullptr;  // second half of the d_pair_ref allocation
     std::vector<uint32_t> h_pair_ref;
     bool pair_ref_dirty = true;
     std::tuple<uint32_t, uint32_t, uint32_t> pool_key{0, 0, 0};  // (w, h, ring slot) when owned by a context's scratch pool
@@ -111,8 +112,11 @@ struct ce_batch {
     ce_dev_scores *h_scores = nullptr;  // pinned
     bool ssim2_ready = false;
     // XCD-aware work lists of the level-0 row / column pass (ssim2.hip): launch id -> (block, channel, pair)
-    uint2 *d_work_h = nullptr, *d_work_v = nullptr;
+    uint2 *d_work_h = nullptr, *d_work_v = nullptr;    // level 0
+    uint2 *d_work_ht = nullptr, *d_work_vt = nullptr;  // the merged launch of levels 1..
     uint32_t work_len_h = 0, work_len_v = 0, work_cap_h = 0, work_cap_v = 0, work_version = ~0u, work_pairs = 0;
+    uint32_t work_len_ht = 0, work_len_vt = 0, work_cap_ht = 0, work_cap_vt = 0, work_version_t = ~0u, work_pairs_t = 0;
+    uint32_t work_blk_ht = 0, work_blk_vt = 0;
     // reference handles (ce_ref_*): the references' XYB pyramid of the last SSIMULACRA2 run stays valid
     // until a reference is replaced, so later compares only build the distorted side
     bool keep_ref_pyramid = false;

@@ -236,7 +236,6 @@ constexpr int HB_LOADS = 2 * HB_ROWS * 8;                    // float4 loads per
 constexpr int HB_LSLOTS = (HB_LOADS + 63) / 64;             // load slots per lane of the loader wave
 static_assert(HB_ROWS * CE_SSIM2_STREAMS <= HB_THREADS, "one task per thread");
 constexpr int HB_HALF = HB_CW * HB_LD;
-constexpr int HB_TASKS = HB_ROWS * CE_SSIM2_STREAMS;  // 240 (stream, row) lanes
 constexpr int HB_STORES = CE_SSIM2_STREAMS * HB_ROWS * (HB_CW / 4);  // float4 stores per chunk: 1920
 
 // Every stream is in[i] = P[i] * Q[i] with (P, Q) = (a, 1), (b, 1), (a, a), (b, b), (a, b).
@@ -312,24 +311,24 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
                                                                 const uint32_t *__restrict__ pair_ref,
                                                                 float *__restrict__ hbuf, uint32_t w, uint32_t h,
                                                                 uint32_t pitch, size_t plane, uint32_t max_refs,
-                                                                rg_consts rg, lvl_table tab, const uint2 *__restrict__ work)
+                                                                rg_consts rg, lvl_table tab, const uint2 *__restrict__ work,
+                                                                const uint32_t *__restrict__ pair_first)
 {
     __shared__ float s_in[2][2 * HB_HALF];  // [plane a|b][half][column][row]
     __shared__ float s_out[CE_SSIM2_STREAMS * HB_HALF];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint32_t bx = blockIdx.x;
+    uint32_t bx = blockIdx.x, c = blockIdx.y, p = blockIdx.z;
+    if (work) {  // XCD-aware 1-D launch: the work list says which (block, channel, pair) this id is
+        const uint2 wi = work[blockIdx.x];
+        if (wi.x == ~0u) return;  // padding entry
+        bx = wi.x & 0xffffu, c = wi.x >> 16, p = wi.y;
+    }
     if (LEVEL < 0) {  // merged launch: which level does this block belong to?
         uint32_t l = 0;
         while (l + 1 < tab.n && bx >= tab.blk_end[l]) l++;
         bx -= l ? tab.blk_end[l - 1] : 0;
         xyb = tab.xyb[l], hbuf = tab.hbuf[l];
         w = tab.w[l], h = tab.h[l], pitch = tab.pitch[l], plane = tab.plane[l];
-    }
-    uint32_t c = blockIdx.y, p = blockIdx.z;
-    if (LEVEL == 0 && work) {  // XCD-aware 1-D launch: the work list says which (block, channel, pair) this id is
-        const uint2 wi = work[blockIdx.x];
-        if (wi.x == ~0u) return;  // padding entry
-        bx = wi.x & 0xffffu, c = wi.x >> 16, p = wi.y;
     }
     const uint32_t y0 = bx * HB_ROWS;
     const float *ga = xyb + ((size_t)pair_ref[p] * 3 + c) * plane;
@@ -384,9 +383,14 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
     if (n_chunks > 1) load_chunk(1);
     __syncthreads();
 
-    // filter task of this thread
-    const bool worker = tid < HB_TASKS;
-    const uint32_t ts = worker ? tid / HB_ROWS : 0, tr = worker ? tid % HB_ROWS : 0;
+    // filter task of this thread.  The reference-only streams (a, a*a) are the same for every distorted image of a
+    // reference: only the reference's first pair (pair_first[p] == p) produces them, the other pairs run the three
+    // streams that involve b - the column pass reads streams 0 and 2 from the first pair's planes.
+    const bool full = pair_first[p] == p;
+    const uint32_t n_jobs = full ? CE_SSIM2_STREAMS : 3;
+    const bool worker = tid < n_jobs * HB_ROWS;
+    const uint32_t tj = worker ? tid / HB_ROWS : 0, tr = worker ? tid % HB_ROWS : 0;
+    const uint32_t ts = full ? tj : (tj == 0 ? 1u : tj + 2u);  // jobs of a later pair: streams 1, 3, 4
     const bool plain = ts < 2;
     const float *sp = &s_in[(ts == 1 || ts == 3) ? 1 : 0][tr];
     const float *sq = &s_in[(ts == 2) ? 0 : 1][tr];  // a*a -> a, b*b and a*b -> b (ignored when plain)
@@ -410,8 +414,9 @@ __global__ __launch_bounds__(HB_THREADS) void k_ssim2_hblur_lds(const float *__r
 #pragma unroll
             for (int it = 0; it < (HB_STORES + 191) / 192; it++) {
                 const uint32_t idx = it * 192 + tid;
-                if (idx >= (uint32_t)HB_STORES) break;
-                const uint32_t os = idx / (HB_ROWS * 8), rem = idx % (HB_ROWS * 8), orow = rem >> 3, oq = rem & 7;
+                if (idx >= n_jobs * (HB_ROWS * 8)) break;
+                const uint32_t oj = idx / (HB_ROWS * 8), rem = idx % (HB_ROWS * 8), orow = rem >> 3, oq = rem & 7;
+                const uint32_t os = full ? oj : (oj == 0 ? 1u : oj + 2u);
                 const float *src = &s_out[os * HB_HALF + (4 * oq) * HB_LD + orow];
                 const float4 v = make_float4(src[0], src[HB_LD], src[2 * HB_LD], src[3 * HB_LD]);
                 if (y0 + orow < h)
@@ -508,10 +513,15 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
                                                         double *__restrict__ partials, uint32_t w, uint32_t h,
                                                         uint32_t pitch, size_t plane, uint32_t max_refs, uint32_t scale,
                                                         uint32_t max_vblocks, rg_consts rg, lvl_table tab,
-                                                        const uint2 *__restrict__ work)
+                                                        const uint2 *__restrict__ work, const uint32_t *__restrict__ pair_first)
 {
     __shared__ __attribute__((aligned(16))) float ring[2 * VB_GROUP];
-    uint32_t bx = blockIdx.x;
+    uint32_t bx = blockIdx.x, c = blockIdx.y, p = blockIdx.z;
+    if (work) {  // XCD-aware 1-D launch
+        const uint2 wi = work[blockIdx.x];
+        if (wi.x == ~0u) return;
+        bx = wi.x & 0xffffu, c = wi.x >> 16, p = wi.y;
+    }
     if (LEVEL < 0) {  // merged launch: which level does this block belong to?
         uint32_t l = 0;
         while (l + 1 < tab.n && bx >= tab.blk_end[l]) l++;
@@ -520,15 +530,11 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
         w = tab.w[l], h = tab.h[l], pitch = tab.pitch[l], plane = tab.plane[l];
         scale = tab.first_level + l;
     }
-    uint32_t c = blockIdx.y, p = blockIdx.z;
-    if (LEVEL == 0 && work) {  // XCD-aware 1-D launch
-        const uint2 wi = work[blockIdx.x];
-        if (wi.x == ~0u) return;
-        bx = wi.x & 0xffffu, c = wi.x >> 16, p = wi.y;
-    }
     const uint32_t lane = threadIdx.x, x0 = bx * 64;
     const bool active = x0 + lane < w;
     const float *hb = hbuf + ((size_t)p * 3 + c) * CE_SSIM2_STREAMS * plane + x0;
+    // streams 0 and 2 (blurred a, a*a) exist once per reference, in the planes of its first pair
+    const float *hb_ref = hbuf + ((size_t)pair_first[p] * 3 + c) * CE_SSIM2_STREAMS * plane + x0;
     const float *xa = xyb + ((size_t)pair_ref[p] * 3 + c) * plane + x0;
     const float *xb = xyb + ((size_t)(max_refs + p) * 3 + c) * plane + x0;
     const uint32_t dr = lane >> 4, dc = (lane & 15) * 4;  // DMA: 16 lanes x 16 B per row, 4 rows per instruction
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(64) void k_ssim2_vblur_dma(const float *__restrict_
         const size_t off = (size_t)row * pitch + dc;
 #pragma unroll
         for (int s = 0; s < CE_SSIM2_STREAMS; s++)
-            __builtin_amdgcn_global_load_lds((gptr)(hb + (size_t)s * plane + off), (lptr)(dst + s * VB_SLOT), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(((s == 0 || s == 2) ? hb_ref : hb) + (size_t)s * plane + off), (lptr)(dst + s * VB_SLOT), 16, 0, 0);
         const int rx = 4 * g - 4 + (int)dr;
         const size_t offx = (size_t)min((uint32_t)max(rx, 0), h - 1) * pitch + dc;
         __builtin_amdgcn_global_load_lds((gptr)(xa + offx), (lptr)(dst + 5 * VB_SLOT), 16, 0, 0);
@@ -779,6 +785,27 @@ static int build_work_lists(ce_batch *b, uint32_t n_pairs, uint32_t hblk, uint32
     return CE_OK;
 }
 
+// the same for the merged launch of levels 1..: the block index runs over the blocks of all those levels
+static int build_tail_lists(ce_batch *b, uint32_t n_pairs, uint32_t hblk, uint32_t vblk)
+{
+    if (b->work_version_t == b->pair_ref_version && b->work_pairs_t == n_pairs && b->work_blk_ht == hblk && b->work_blk_vt == vblk &&
+        b->d_work_ht)
+        return CE_OK;
+    if (hblk > 0xffffu || vblk > 0xffffu) {
+        b->ctx->err = "SSIMULACRA2: image too large for the block index of the work list";
+        return CE_ERR_INVALID_ARG;
+    }
+    int rc = build_one_list(b, n_pairs, hblk, &b->d_work_ht, &b->work_len_ht, &b->work_cap_ht);
+    if (rc != CE_OK) return rc;
+    rc = build_one_list(b, n_pairs, vblk, &b->d_work_vt, &b->work_len_vt, &b->work_cap_vt);
+    if (rc != CE_OK) return rc;
+    b->work_version_t = b->pair_ref_version;
+    b->work_pairs_t = n_pairs;
+    b->work_blk_ht = hblk;
+    b->work_blk_vt = vblk;
+    return CE_OK;
+}
+
 int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs)
 {
     ce_ctx *ctx = b->ctx;
@@ -793,9 +820,9 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                         b->ssim2_ref_levels == std::min(b->n_scales, b->debug_max_scales);
     const uint32_t z0 = cached ? n_refs_used : 0;
     using hblur_fn = void (*)(const float *, const uint32_t *, float *, uint32_t, uint32_t, uint32_t, size_t, uint32_t,
-                              rg_consts, lvl_table, const uint2 *);
+                              rg_consts, lvl_table, const uint2 *, const uint32_t *);
     using vblur_fn = void (*)(const float *, const float *, const uint32_t *, double *, uint32_t, uint32_t, uint32_t,
-                              size_t, uint32_t, uint32_t, uint32_t, rg_consts, lvl_table, const uint2 *);
+                              size_t, uint32_t, uint32_t, uint32_t, rg_consts, lvl_table, const uint2 *, const uint32_t *);
     const hblur_fn h_l0 = k_ssim2_hblur_lds<0>, h_tail = k_ssim2_hblur_lds<-1>;
     const vblur_fn v_l0 = k_ssim2_vblur_dma<0>, v_tail = k_ssim2_vblur_dma<-1>;
     scale_geom g{};
@@ -832,10 +859,11 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             rc = build_work_lists(b, n_pairs, hblk, vblk);
             if (rc != CE_OK) return rc;
             CE_LAUNCH_ON(ctx, s0, "ssim2_hblur_L0", h_l0, dim3(b->work_len_h), dim3(HB_THREADS), 0, b->d_xyb[0], b->d_pair_ref,
-                         b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab, (const uint2 *)b->d_work_h);
+                         b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab, (const uint2 *)b->d_work_h,
+                         (const uint32_t *)b->d_pair_first);
             CE_LAUNCH_ON(ctx, s0, "ssim2_vblur_ssim_L0", v_l0, dim3(b->work_len_v), dim3(64), 0, b->d_hbuf[0], b->d_xyb[0],
                          b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab,
-                         (const uint2 *)b->d_work_v);
+                         (const uint2 *)b->d_work_v, (const uint32_t *)b->d_pair_first);
             if (s0 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[0], s0));
         } else {
             const uint32_t l = tab.n++;
@@ -856,12 +884,14 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             CE_HIP(ctx, hipEventRecord(b->ev_prep[1], ctx->stream));
             CE_HIP(ctx, hipStreamWaitEvent(s1, b->ev_prep[1], 0));
         }
-        CE_LAUNCH_ON(ctx, s1, "ssim2_hblur_L1-5", h_tail, dim3(tab.blk_end[tab.n - 1], 3, n_pairs), dim3(HB_THREADS), 0,
+        rc = build_tail_lists(b, n_pairs, tab.blk_end[tab.n - 1], tab_v.blk_end[tab_v.n - 1]);
+        if (rc != CE_OK) return rc;
+        CE_LAUNCH_ON(ctx, s1, "ssim2_hblur_L1-5", h_tail, dim3(b->work_len_ht), dim3(HB_THREADS), 0,
                      (const float *)nullptr, b->d_pair_ref, (float *)nullptr, 0u, 0u, 0u, (size_t)0, b->max_refs, rg, tab,
-                     (const uint2 *)nullptr);
-        CE_LAUNCH_ON(ctx, s1, "ssim2_vblur_ssim_L1-5", v_tail, dim3(tab_v.blk_end[tab_v.n - 1], 3, n_pairs), dim3(64), 0,
+                     (const uint2 *)b->d_work_ht, (const uint32_t *)b->d_pair_first);
+        CE_LAUNCH_ON(ctx, s1, "ssim2_vblur_ssim_L1-5", v_tail, dim3(b->work_len_vt), dim3(64), 0,
                      (const float *)nullptr, (const float *)nullptr, b->d_pair_ref, b->d_partials, 0u, 0u, 0u, (size_t)0, b->max_refs,
-                     0u, b->max_vblocks, rg, tab_v, (const uint2 *)nullptr);
+                     0u, b->max_vblocks, rg, tab_v, (const uint2 *)b->d_work_vt, (const uint32_t *)b->d_pair_first);
         if (s1 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[1], s1));
     }
     if (!ctx->prof_serial) {
