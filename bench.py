@@ -303,6 +303,11 @@ def main():
             "pipeline_achieved": round(ssim2_step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "pipeline_frac": round(ssim2_step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "pipeline_bytes_per_px0": round(ssim2_step_bytes / px0, 1),
+            # the same two fractions on SURVEY.md §8(d)'s uncached-pair counts (66 B per pass, 210 B per pixel), for comparison
+            "uncached_pair_model": {
+                "frac": round(SSIM2_PASS_BYTES_L0 * px0 / n_launch_per_step / avg_s / 1e9 / HBM_PEAK_GBPS, 4) if name.endswith("_L0") else None,
+                "pipeline_frac": round(SSIM2_BYTES_PER_PX0_TOTAL * px0 / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            },
         }
         if solo:
             sn, sms = solo[name]
