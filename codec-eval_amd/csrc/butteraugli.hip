@@ -591,14 +591,22 @@ __global__ __launch_bounds__(TPB, 4) void k_ba_malta_l2(const float *__restrict_
             const malta_params mp = mb.p[c][band];
             const uint32_t band_plane = (band == 0 ? UHF0 : band == 1 ? HF0 : MF0) + c;
             const float *pa = a + (size_t)band_plane * g.plane, *pb = b + (size_t)band_plane * g.plane;
-            for (int i = threadIdx.x; i < ML * ML; i += TPB) {
-                const int lx = i % ML, ly = i / ML, gx = x0 + lx, gy = y0 + ly;
-                float v = 0.0f;
-                if (gx >= 0 && gy >= 0 && gx < (int)g.w && gy < (int)g.h) {
+            // the tile starts 4 columns left of a 64-column boundary: every group of four is one aligned float4 of the row
+            for (int i = threadIdx.x; i < ML * (ML / 4); i += TPB) {
+                const int ly = i / (ML / 4), lq = i % (ML / 4), gx = x0 + 4 * lq, gy = y0 + ly;
+                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+                const bool in = gx >= 0 && gy >= 0 && gx < (int)g.pitch && gy < (int)g.h;
+                if (in) {
                     const size_t o = (size_t)gy * g.pitch + gx;
-                    v = malta_pre_diff(pa[o], pb[o], mp);
+                    va = *reinterpret_cast<const float4 *>(pa + o);
+                    vb = *reinterpret_cast<const float4 *>(pb + o);
                 }
-                s[i] = v;
+                float4 r;
+                r.x = (in && gx < (int)g.w) ? malta_pre_diff(va.x, vb.x, mp) : 0.0f;
+                r.y = (in && gx + 1 < (int)g.w) ? malta_pre_diff(va.y, vb.y, mp) : 0.0f;
+                r.z = (in && gx + 2 < (int)g.w) ? malta_pre_diff(va.z, vb.z, mp) : 0.0f;
+                r.w = (in && gx + 3 < (int)g.w) ? malta_pre_diff(va.w, vb.w, mp) : 0.0f;
+                *reinterpret_cast<float4 *>(s + ly * ML + 4 * lq) = r;
             }
             __syncthreads();
 #pragma unroll 1
