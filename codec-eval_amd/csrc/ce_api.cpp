@@ -237,6 +237,7 @@ void ce_batch_destroy(ce_batch *b)
     hipFree(b->d_wide);
     if (b->ev_up) hipEventDestroy(b->ev_up);
     if (b->ev_run) hipEventDestroy(b->ev_run);
+    if (b->ev_fork) hipEventDestroy(b->ev_fork);
     hipFree(b->d_refs);
     hipFree(b->d_refs_rt);
     hipFree(b->d_tests);
@@ -252,6 +253,8 @@ void ce_batch_destroy(ce_batch *b)
         hipFree(b->d_xyb[l]);
         hipFree(b->d_hbuf[l]);
         if (b->lvl_stream[l]) hipStreamSynchronize(b->lvl_stream[l]), hipStreamDestroy(b->lvl_stream[l]);
+        if (l < 3 && b->metric_stream[l]) hipStreamSynchronize(b->metric_stream[l]), hipStreamDestroy(b->metric_stream[l]);
+        if (l < 3 && b->ev_join[l]) hipEventDestroy(b->ev_join[l]);
         if (b->ev_prep[l]) hipEventDestroy(b->ev_prep[l]);
         if (b->ev_done[l]) hipEventDestroy(b->ev_done[l]);
     }
@@ -523,16 +526,44 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         int rc = ce_launch_psnr(b, d_refs, n_pairs);
         if (rc != CE_OK) return rc;
     }
-    if ((metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8) {
-        int rc = ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs);
+    // The three perceptual metrics are independent chains over their own buffers.  When a launch runs more than one,
+    // each chain goes to its own stream (forked from / joined back to the context's stream): DSSIM's image builder and
+    // Butteraugli's Malta kernel are VALU-bound, the SSIMULACRA2 passes HBM-bound, and side by side they fill each
+    // other's idle resource.  The serial profiling mode keeps everything on one stream.
+    const bool run_ssim2 = (metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8;
+    const bool run_dssim = (metric_mask & CE_METRIC_DSSIM) != 0;
+    const bool run_ba = (metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8;
+    const bool fork = !ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1;
+    hipStream_t base = ctx->stream;
+    if (fork) {
+        if (!b->ev_fork) CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+        CE_HIP(ctx, hipEventRecord(b->ev_fork, base));
+    }
+    auto chain = [&](int k, auto &&launch) -> int {
+        if (!fork) return launch();
+        if (!b->metric_stream[k]) {
+            CE_HIP(ctx, hipStreamCreateWithFlags(&b->metric_stream[k], hipStreamNonBlocking));
+            CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming));
+        }
+        CE_HIP(ctx, hipStreamWaitEvent(b->metric_stream[k], b->ev_fork, 0));
+        ctx->stream = b->metric_stream[k];  // the chain's launches go to "the context's stream"
+        const int rc = launch();
+        ctx->stream = base;
+        if (rc != CE_OK) return rc;
+        CE_HIP(ctx, hipEventRecord(b->ev_join[k], b->metric_stream[k]));
+        CE_HIP(ctx, hipStreamWaitEvent(base, b->ev_join[k], 0));
+        return CE_OK;
+    };
+    if (run_ssim2) {
+        int rc = chain(0, [&] { return ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs); });
         if (rc != CE_OK) return rc;
     }
-    if (metric_mask & CE_METRIC_DSSIM) {
-        int rc = ce_launch_dssim(b, d_refs, n_refs_used, n_pairs);
+    if (run_dssim) {
+        int rc = chain(1, [&] { return ce_launch_dssim(b, d_refs, n_refs_used, n_pairs); });
         if (rc != CE_OK) return rc;
     }
-    if ((metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8) {
-        int rc = ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target);
+    if (run_ba) {
+        int rc = chain(2, [&] { return ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target); });
         if (rc != CE_OK) return rc;
     }
     b->last_n_pairs = n_pairs;

@@ -104,6 +104,9 @@ struct ce_batch {
     // the levels' row/column passes are independent once the front end has produced the level's XYB:
     // each level runs on its own stream, fenced by events against the front end and the final reduction
     hipStream_t lvl_stream[CE_MAX_SCALES] = {};
+    // one stream per metric chain when a launch runs several of them (SSIMULACRA2, DSSIM, Butteraugli side by side)
+    hipStream_t metric_stream[3] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
     hipEvent_t ev_prep[CE_MAX_SCALES] = {}, ev_done[CE_MAX_SCALES] = {};
     double *d_partials = nullptr;      // [pairs][scales][3][max_blocks][6]
     uint32_t max_vblocks = 0;
