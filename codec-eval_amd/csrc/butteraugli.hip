@@ -380,20 +380,40 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
     constexpr int NP = EPI == EPI_HF ? 2 : 3;
     // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
     constexpr int off = LEN / 2, TW = 64, TR = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
-    __shared__ float tile[RAW * TW];
+    __shared__ __attribute__((aligned(16))) float tile[RAW * TW];
     const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
     const int c = threadIdx.x & 63, wv = threadIdx.x >> 6, gx = x0 + c;
     const bool col_live = gx < (int)g.w;
     float res[NP][PARTS][BW_OUT];
+    // The tile of plane q+1 is fetched (aligned float4 pieces of the rows, zero outside the image) into registers
+    // while plane q is filtered: NF float4 per thread.
+    constexpr int NF = (RAW * (TW / 4) + TPB - 1) / TPB;
+    float4 pf[NF];
+    auto fetch = [&](int q) {
+        const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes of this slot
+#pragma unroll
+        for (int m = 0; m < NF; m++) {
+            const int i = m * TPB + (int)threadIdx.x, r = i / (TW / 4), X = x0 + 4 * (i % (TW / 4)), Y = y0 - off + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < RAW && Y >= 0 && Y < (int)g.h && X < (int)g.pitch) v = *reinterpret_cast<const float4 *>(p + (size_t)Y * g.pitch + X);
+            v.x = X < (int)g.w ? v.x : 0.0f;
+            v.y = X + 1 < (int)g.w ? v.y : 0.0f;
+            v.z = X + 2 < (int)g.w ? v.z : 0.0f;
+            v.w = X + 3 < (int)g.w ? v.w : 0.0f;
+            pf[m] = v;
+        }
+    };
+    fetch(0);
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-        const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes of this slot
         if (q) __syncthreads();
-        for (int i = threadIdx.x; i < RAW * TW; i += TPB) {
-            const int r = i / TW, cc = i % TW, X = x0 + cc, Y = y0 - off + r;
-            tile[i] = (Y >= 0 && Y < (int)g.h && X < (int)g.w) ? p[(size_t)Y * g.pitch + X] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < NF; m++) {
+            const int i = m * TPB + (int)threadIdx.x;
+            if (i < RAW * (TW / 4)) *reinterpret_cast<float4 *>(tile + 4 * i) = pf[m];
         }
+        if (q + 1 < NP) fetch(q + 1);
         __syncthreads();
 #pragma unroll
         for (int part = 0; part < PARTS; part++) {
