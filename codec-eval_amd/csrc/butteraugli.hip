@@ -128,6 +128,7 @@ __device__ __forceinline__ float border_scale(const blur_kernel &bk, int pos, in
 // is one v_pk_mul_f32 + one v_pk_add_f32 (two IEEE multiplies / adds: bit-identical to the scalar tap loop, taps
 // still summed in ascending order).
 typedef float ba_f2 __attribute__((ext_vector_type(2)));
+constexpr int BH_TILES = 4;  // 8-row tiles per block of the row blur
 
 template <int LEN>
 __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
@@ -140,56 +141,80 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
     const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
     const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
     const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
-    for (int i = threadIdx.x; i < TR * (RAW / 4); i += TPB) {
-        const int r = i / (RAW / 4), c = 4 * (i % (RAW / 4)), gx = x0 - LEFT + c, gy = y0 + r;
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (gx >= 0 && gx < (int)g.pitch && gy < (int)g.h) {  // 16-byte aligned, whole float4 inside the padded row
-            v = *reinterpret_cast<const float4 *>(p + (size_t)gy * g.pitch + gx);
-            if (gx + 3 >= (int)g.w) {  // the row's padding is not part of the image
-                if (gx + 0 >= (int)g.w) v.x = 0.0f;
-                if (gx + 1 >= (int)g.w) v.y = 0.0f;
-                if (gx + 2 >= (int)g.w) v.z = 0.0f;
-                v.w = 0.0f;
+    const int x0 = blockIdx.x * TW;
+    // A block walks BH_TILES consecutive 8-row tiles; the next tile's float4 pieces are fetched into registers while
+    // the current one is filtered out of LDS.
+    constexpr int NF = (TR * (RAW / 4) + TPB - 1) / TPB;
+    float4 pf[NF];
+    auto fetch = [&](int y0) {
+#pragma unroll
+        for (int m = 0; m < NF; m++) {
+            const int i = m * TPB + (int)threadIdx.x, r = i / (RAW / 4), c = 4 * (i % (RAW / 4)), gx = x0 - LEFT + c, gy = y0 + r;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (r < TR && gx >= 0 && gx < (int)g.pitch && gy < (int)g.h) {  // 16-byte aligned, whole float4 inside the padded row
+                v = *reinterpret_cast<const float4 *>(p + (size_t)gy * g.pitch + gx);
+                if (gx + 3 >= (int)g.w) {  // the row's padding is not part of the image
+                    if (gx + 0 >= (int)g.w) v.x = 0.0f;
+                    if (gx + 1 >= (int)g.w) v.y = 0.0f;
+                    if (gx + 2 >= (int)g.w) v.z = 0.0f;
+                    v.w = 0.0f;
+                }
             }
+            pf[m] = v;
         }
-        float *t = &tile[r * ROWF + c + (c >> 3)];  // c is a multiple of 4: the four floats stay inside one group of 8
-        t[0] = v.x, t[1] = v.y, t[2] = v.z, t[3] = v.w;
-    }
-    __syncthreads();
-    const int r = threadIdx.x >> 5, cx = threadIdx.x & 31, gy = y0 + r, gx0 = x0 + 8 * cx;
-    if (gy >= (int)g.h || gx0 >= (int)g.w) return;
+    };
+    const int r = threadIdx.x >> 5, cx = threadIdx.x & 31, gx0 = x0 + 8 * cx;
     constexpr int NV = BW_OUT + LEN - 1, NP = (NV + 1) / 2;
     const float *row = &tile[r * ROWF + 9 * cx];  // element j of the window sits at j + SH + ((j + SH) >> 3)
     auto at = [&](int j) { return row[(j + SH) + ((j + SH) >> 3)]; };
-    ba_f2 pe[NP], po[NP];
+    const int y_first = blockIdx.y * (TR * BH_TILES);
+    fetch(y_first);
+#pragma unroll 1
+    for (int t = 0; t < BH_TILES; t++) {
+        const int y0 = y_first + t * TR;
+        if (y0 >= (int)g.h) break;  // block-uniform
+        if (t) __syncthreads();     // the previous tile has been read
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-        pe[i] = ba_f2{at(2 * i), 2 * i + 1 < NV ? at(2 * i + 1) : 0.0f};
-        po[i] = ba_f2{2 * i + 1 < NV ? at(2 * i + 1) : 0.0f, 2 * i + 2 < NV ? at(2 * i + 2) : 0.0f};
-    }
-    float *dst = out + ((size_t)unit * so.per_unit + so.first + k) * g.plane + (size_t)gy * g.pitch + gx0;
-    float res[BW_OUT];
-#pragma unroll
-    for (int op = 0; op < BW_OUT / 2; op++) {
-        ba_f2 sum = {0.0f, 0.0f};
-#pragma unroll
-        for (int j = 0; j < LEN; j++) {
-            const int idx = 2 * op + j;
-            const ba_f2 src = (idx & 1) ? po[idx >> 1] : pe[idx >> 1];
-            const ba_f2 prod = src * ba_f2{bk.k[j], bk.k[j]};
-            sum = sum + prod;
+        for (int m = 0; m < NF; m++) {
+            const int i = m * TPB + (int)threadIdx.x, rr = i / (RAW / 4), c = 4 * (i % (RAW / 4));
+            if (rr < TR) {
+                float *tp = &tile[rr * ROWF + c + (c >> 3)];  // c is a multiple of 4: the four floats stay inside one group of 8
+                tp[0] = pf[m].x, tp[1] = pf[m].y, tp[2] = pf[m].z, tp[3] = pf[m].w;
+            }
         }
-        res[2 * op] = sum.x * border_scale<LEN>(bk, gx0 + 2 * op, (int)g.w, inv_wsum);
-        res[2 * op + 1] = sum.y * border_scale<LEN>(bk, gx0 + 2 * op + 1, (int)g.w, inv_wsum);
-    }
-    if (gx0 + BW_OUT <= (int)g.w) {  // rows are 128-byte aligned and gx0 is a multiple of 8
-        *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
-    } else {
+        if (t + 1 < BH_TILES && y0 + TR < (int)g.h) fetch(y0 + TR);
+        __syncthreads();
+        const int gy = y0 + r;
+        if (gy >= (int)g.h || gx0 >= (int)g.w) continue;
+        ba_f2 pe[NP], po[NP];
 #pragma unroll
-        for (int o = 0; o < BW_OUT; o++)
-            if (gx0 + o < (int)g.w) dst[o] = res[o];
+        for (int i = 0; i < NP; i++) {
+            pe[i] = ba_f2{at(2 * i), 2 * i + 1 < NV ? at(2 * i + 1) : 0.0f};
+            po[i] = ba_f2{2 * i + 1 < NV ? at(2 * i + 1) : 0.0f, 2 * i + 2 < NV ? at(2 * i + 2) : 0.0f};
+        }
+        float *dst = out + ((size_t)unit * so.per_unit + so.first + k) * g.plane + (size_t)gy * g.pitch + gx0;
+        float res[BW_OUT];
+#pragma unroll
+        for (int op = 0; op < BW_OUT / 2; op++) {
+            ba_f2 sum = {0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < LEN; j++) {
+                const int idx = 2 * op + j;
+                const ba_f2 src = (idx & 1) ? po[idx >> 1] : pe[idx >> 1];
+                const ba_f2 prod = src * ba_f2{bk.k[j], bk.k[j]};
+                sum = sum + prod;
+            }
+            res[2 * op] = sum.x * border_scale<LEN>(bk, gx0 + 2 * op, (int)g.w, inv_wsum);
+            res[2 * op + 1] = sum.y * border_scale<LEN>(bk, gx0 + 2 * op + 1, (int)g.w, inv_wsum);
+        }
+        if (gx0 + BW_OUT <= (int)g.w) {  // rows are 128-byte aligned and gx0 is a multiple of 8
+            *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(res[4], res[5], res[6], res[7]);
+        } else {
+#pragma unroll
+            for (int o = 0; o < BW_OUT; o++)
+                if (gx0 + o < (int)g.w) dst[o] = res[o];
+        }
     }
 }
 
@@ -900,7 +925,7 @@ int launch_blur_len(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g
                     const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot)
 {
     const float inv = inv_weight_sum(bk);
-    const dim3 gh((g.w + 255) / 256, (g.h + 7) / 8, units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
+    const dim3 gh((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
     CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot);
     CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot);
     return CE_OK;
@@ -1027,7 +1052,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                 ctx->err = "unexpected blur kernel length";
                 return CE_ERR_BACKEND;
             }
-            const dim3 gh3((g.w + 255) / 256, (g.h + 7) / 8, n_slots * 3), gh2(gh3.x, gh3.y, n_slots * 2);
+            const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), n_slots * 3), gh2(gh3.x, gh3.y, n_slots * 2);
             const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, n_slots);
             CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1);
