@@ -805,6 +805,7 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict
     diffmap[po] = sqrtf(mc_dc + mc_ac);
 }
 
+constexpr int BF_ROWS = 32;  // rows per block of k_ba_final
 // AddSupersampled2x (weight 0.5) fused with the final reductions: max, sum d^3, d^6, d^12
 __global__ __launch_bounds__(TPB) void k_ba_final(float *__restrict__ diffmap, const float *__restrict__ sub, geom g, geom gs,
                                                   int has_sub, float *__restrict__ blk_max, double *__restrict__ blk_sums,
@@ -813,24 +814,29 @@ __global__ __launch_bounds__(TPB) void k_ba_final(float *__restrict__ diffmap, c
     __shared__ float s_max[TPB / 64];
     __shared__ double s_sum[3][TPB / 64];
     const uint32_t p = blockIdx.z;
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    float d = 0.0f;
+    // block = 64 columns x 32 rows, a thread walks 8 rows (stride 4): one block reduction per 2048 pixels
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    float m = 0.0f;  // the diffmap is non-negative
     double s3 = 0.0, s6 = 0.0, s12 = 0.0;
-    if (x < g.w && y < g.h) {
-        const size_t o = (size_t)p * g.plane + (size_t)y * g.pitch + x;
-        d = diffmap[o];
-        if (has_sub) {
-            const float kHeuristicMixingValue = 0.3f, wgt = 0.5f;
-            d *= 1.0f - kHeuristicMixingValue * wgt;
-            d += wgt * sub[(size_t)p * gs.plane + (size_t)(y / 2) * gs.pitch + x / 2];
-            diffmap[o] = d;
+#pragma unroll
+    for (int k = 0; k < BF_ROWS / 4; k++) {
+        const uint32_t y = blockIdx.y * BF_ROWS + 4 * k + (threadIdx.x >> 6);
+        if (x < g.w && y < g.h) {
+            const size_t o = (size_t)p * g.plane + (size_t)y * g.pitch + x;
+            float d = diffmap[o];
+            if (has_sub) {
+                const float kHeuristicMixingValue = 0.3f, wgt = 0.5f;
+                d *= 1.0f - kHeuristicMixingValue * wgt;
+                d += wgt * sub[(size_t)p * gs.plane + (size_t)(y / 2) * gs.pitch + x / 2];
+                diffmap[o] = d;
+            }
+            const double dd = d, d3 = dd * dd * dd, d6 = d3 * d3;
+            s3 += d3;
+            s6 += d6;
+            s12 += d6 * d6;
+            m = fmaxf(m, d);
         }
-        const double dd = d, d3 = dd * dd * dd, d6 = d3 * d3;
-        s3 = d3;
-        s6 = d6;
-        s12 = d6 * d6;
     }
-    float m = d;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         m = fmaxf(m, __shfl_down(m, off, 64));
@@ -1088,7 +1094,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     const bool has_sub = b->ba_levels == 2;
     const auto &d1 = b->ba[has_sub ? 1 : 0];
     const geom g1{d1.w, d1.h, d1.pitch, d1.plane};
-    const dim3 gf((d0.w + 63) / 64, (d0.h + 3) / 4, n_pairs);
+    const dim3 gf((d0.w + 63) / 64, (d0.h + BF_ROWS - 1) / BF_ROWS, n_pairs);
     CE_LAUNCH(ctx, "ba_final", k_ba_final, gf, dim3(TPB), 0, b->ba_diff[0], b->ba_diff[has_sub ? 1 : 0], g0, g1, has_sub ? 1 : 0,
               b->ba_blk_max, b->ba_blk_sums, b->ba_blocks);
     CE_LAUNCH(ctx, "ba_score", k_ba_score, dim3(n_pairs), dim3(TPB), 0, b->ba_blk_max, b->ba_blk_sums, b->d_scores, b->ba_pnorm,

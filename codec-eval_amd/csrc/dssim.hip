@@ -341,6 +341,7 @@ __global__ __launch_bounds__(TPB) void k_dssim_avg(const double *__restrict__ pa
 }
 
 // ---- mean absolute deviation of the SSIM map from avg ------------------------------------------------------
+constexpr int AD_ROWS = 32;  // rows per block
 __global__ __launch_bounds__(TPB) void k_dssim_absdev(const float *__restrict__ map, const double *__restrict__ avg_in,
                                                       double *__restrict__ part, uint32_t w, uint32_t h, uint32_t pitch,
                                                       size_t plane, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
@@ -349,9 +350,14 @@ __global__ __launch_bounds__(TPB) void k_dssim_absdev(const float *__restrict__ 
     const uint32_t p = blockIdx.z;
     double *pp = part + ((size_t)p * n_levels + level) * 2 * n_blocks;
     const double avg = avg_in[(size_t)p * n_levels + level];
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    // block = 64 columns x 32 rows, a thread walks 8 rows (stride 4): one block reduction per 2048 pixels
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     double val = 0.0;
-    if (x < w && y < h) val = fabs(avg - (double)map[(size_t)p * plane + (size_t)y * pitch + x]);
+#pragma unroll
+    for (int k = 0; k < AD_ROWS / 4; k++) {
+        const uint32_t y = blockIdx.y * AD_ROWS + 4 * k + (threadIdx.x >> 6);
+        if (x < w && y < h) val += fabs(avg - (double)map[(size_t)p * plane + (size_t)y * pitch + x]);
+    }
     const double t = block_sum(val, s_red);
     if (threadIdx.x == 0) pp[n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
@@ -464,7 +470,7 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                   b->d_pair_ref, b->ds_map, b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
                   (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
-        const dim3 gp((d.w + 63) / 64, (d.h + 3) / 4, n_pairs);
+        const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);
         CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, b->ds_map, b->ds_level_scores, b->ds_part, d.w, d.h,
                   d.pitch, d.plane, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         g.npix[l] = d.w * d.h;
