@@ -41,8 +41,12 @@ def test_library_exports_every_declared_symbol(ce):
     assert set(declared) <= exported
 
 
-def test_library_has_gfx950_code_object(ce):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", ce.LIB_PATH], capture_output=True, text=True)
+def test_library_has_gfx950_code_object(ce, tmp_path):
+    # llvm-objdump --offloading drops the extracted code objects next to its input: work on a copy
+    import shutil
+
+    lib_copy = shutil.copy(ce.LIB_PATH, tmp_path / "lib.so")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(lib_copy)], capture_output=True, text=True)
     blob = out.stdout + out.stderr
     if "gfx950" not in blob:  # older objdump: fall back to the embedded bundle id
         blob = subprocess.check_output(["strings", ce.LIB_PATH], text=True)
