@@ -17,6 +17,7 @@
 // (k_ba_blur_h / k_ba_blur_v).  Build with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "ce_internal.h"
 
@@ -323,56 +324,66 @@ __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ re
         }
     }
     __syncthreads();
-    // row pass on every in-image row of the region, tile columns only; mirror in GLOBAL coordinates
-    for (int i = threadIdx.x; i < FR * FT; i += TPB) {
-        const int tx = i % FT, ly = i / FT, X = x0 + tx, Y = gy0 + ly;
-        if (X < w && Y >= 0 && Y < h) {
-            const int c0 = X - gx0, m1 = (int)mirror(X - 1, w) - gx0, p1 = (int)mirror(X + 1, w) - gx0,
-                      m2 = (int)mirror(X - 2, w) - gx0, p2 = (int)mirror(X + 2, w) - gx0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float *r = &L[c][ly * FR];
-                H[c][i] = r[c0] * w0 + (r[m1] + r[p1]) * w1 + (r[m2] + r[p2]) * w2;
+    // IN (block-uniform): the whole 36x36 region lies inside the image, so nothing is mirrored and nothing is masked
+    auto stages = [&](auto in_tag) {
+        constexpr bool IN = decltype(in_tag)::value;
+        // row pass on every in-image row of the region, tile columns only; mirror in GLOBAL coordinates
+        for (int i = threadIdx.x; i < FR * FT; i += TPB) {
+            const int tx = i % FT, ly = i / FT, X = x0 + tx, Y = gy0 + ly;
+            if (IN || (X < w && Y >= 0 && Y < h)) {
+                const int c0 = X - gx0;
+                const int m1 = IN ? c0 - 1 : (int)mirror(X - 1, w) - gx0, p1 = IN ? c0 + 1 : (int)mirror(X + 1, w) - gx0,
+                          m2 = IN ? c0 - 2 : (int)mirror(X - 2, w) - gx0, p2 = IN ? c0 + 2 : (int)mirror(X + 2, w) - gx0;
+    #pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float *r = &L[c][ly * FR];
+                    H[c][i] = r[c0] * w0 + (r[m1] + r[p1]) * w1 + (r[m2] + r[p2]) * w2;
+                }
             }
         }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < FT * FT; i += TPB) {
-        const int tx = i % FT, ty = i / FT, X = x0 + tx, Y = y0 + ty;
-        if (X >= w || Y >= h) continue;
-        const int r0 = Y - gy0, rm1 = (int)mirror(Y - 1, h) - gy0, rp1 = (int)mirror(Y + 1, h) - gy0,
-                  rm2 = (int)mirror(Y - 2, h) - gy0, rp2 = (int)mirror(Y + 2, h) - gy0;
-        float bl[3], ln[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float *col = &H[c][tx];
-            bl[c] = col[r0 * FT] * w0 + (col[rm1 * FT] + col[rp1 * FT]) * w1 + (col[rm2 * FT] + col[rp2 * FT]) * w2;
-            ln[c] = L[c][(ty + 2) * FR + tx + 2];
+        __syncthreads();
+        for (int i = threadIdx.x; i < FT * FT; i += TPB) {
+            const int tx = i % FT, ty = i / FT, X = x0 + tx, Y = y0 + ty;
+            if (!IN && (X >= w || Y >= h)) continue;
+            const int r0 = Y - gy0;
+            const int rm1 = IN ? r0 - 1 : (int)mirror(Y - 1, h) - gy0, rp1 = IN ? r0 + 1 : (int)mirror(Y + 1, h) - gy0,
+                      rm2 = IN ? r0 - 2 : (int)mirror(Y - 2, h) - gy0, rp2 = IN ? r0 + 2 : (int)mirror(Y + 2, h) - gy0;
+            float bl[3], ln[3];
+    #pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float *col = &H[c][tx];
+                bl[c] = col[r0 * FT] * w0 + (col[rm1 * FT] + col[rp1 * FT]) * w1 + (col[rm2 * FT] + col[rp2 * FT]) * w2;
+                ln[c] = L[c][(ty + 2) * FR + tx + 2];
+            }
+            const float mn = 1e-4f;
+            float p0, p1v, p2v;
+            opsin_absorbance(bl[0] * intensity_target, bl[1] * intensity_target, bl[2] * intensity_target, p0, p1v, p2v);
+            p0 = p0 > mn ? p0 : mn;
+            p1v = p1v > mn ? p1v : mn;
+            p2v = p2v > mn ? p2v : mn;
+            float s0 = gamma_f(p0) / p0, s1 = gamma_f(p1v) / p1v, s2 = gamma_f(p2v) / p2v;
+            s0 = s0 > mn ? s0 : mn;
+            s1 = s1 > mn ? s1 : mn;
+            s2 = s2 > mn ? s2 : mn;
+            float c0, c1, c2;
+            opsin_absorbance(ln[0] * intensity_target, ln[1] * intensity_target, ln[2] * intensity_target, c0, c1, c2);
+            c0 *= s0;
+            c1 *= s1;
+            c2 *= s2;
+            const float min01 = 1.7557483643287353f, min2 = 12.226454707163354f;
+            c0 = c0 > min01 ? c0 : min01;
+            c1 = c1 > min01 ? c1 : min01;
+            c2 = c2 > min2 ? c2 : min2;
+            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
+            xyb[o] = c0 - c1;
+            xyb[o + g.plane] = c0 + c1;
+            xyb[o + 2 * g.plane] = c2;
         }
-        const float mn = 1e-4f;
-        float p0, p1v, p2v;
-        opsin_absorbance(bl[0] * intensity_target, bl[1] * intensity_target, bl[2] * intensity_target, p0, p1v, p2v);
-        p0 = p0 > mn ? p0 : mn;
-        p1v = p1v > mn ? p1v : mn;
-        p2v = p2v > mn ? p2v : mn;
-        float s0 = gamma_f(p0) / p0, s1 = gamma_f(p1v) / p1v, s2 = gamma_f(p2v) / p2v;
-        s0 = s0 > mn ? s0 : mn;
-        s1 = s1 > mn ? s1 : mn;
-        s2 = s2 > mn ? s2 : mn;
-        float c0, c1, c2;
-        opsin_absorbance(ln[0] * intensity_target, ln[1] * intensity_target, ln[2] * intensity_target, c0, c1, c2);
-        c0 *= s0;
-        c1 *= s1;
-        c2 *= s2;
-        const float min01 = 1.7557483643287353f, min2 = 12.226454707163354f;
-        c0 = c0 > min01 ? c0 : min01;
-        c1 = c1 > min01 ? c1 : min01;
-        c2 = c2 > min2 ? c2 : min2;
-        const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-        xyb[o] = c0 - c1;
-        xyb[o + g.plane] = c0 + c1;
-        xyb[o + 2 * g.plane] = c2;
-    }
+    };
+    if (gx0 >= 0 && gy0 >= 0 && gx0 + FR <= w && gy0 + FR <= h)
+        stages(std::true_type{});
+    else
+        stages(std::false_type{});
 }
 
 // ---- SeparateFrequencies pointwise stages ------------------------------------------------------------------
