@@ -36,6 +36,42 @@ def test_random_shapes_and_contents_all_metrics(gpu_ctx, oracle, ce, workloads):
     assert worst["ssimulacra2"] < 1e-6 and worst["dssim"] < 1e-9 and worst["butteraugli"] < 1e-6, worst
 
 
+def test_random_grids_all_metrics_against_the_oracle(gpu_ctx, oracle, ce, workloads):
+    """Random (shape, references, pairs, bindings) grids with all four metrics in one launch: the SSIMULACRA2 row pass
+    produces the reference-only blur streams once per reference (the other pairs of the reference read them), and the
+    three perceptual metrics run as concurrent kernel chains - every pair must still match the oracle, on the first run
+    and on a repeat with the cached tables."""
+    rng = np.random.default_rng(11)
+    cfg = ce.MetricConfig.all()
+    for it in range(14):
+        w, h = int(rng.integers(8, 260)), int(rng.integers(8, 260))
+        if it % 4 == 0:
+            w, h = int(rng.integers(90, 200)), int(rng.integers(40, 60))
+        R, P = int(rng.integers(1, 5)), int(rng.integers(1, 9))
+        refs = [workloads.make_reference(w, h, int(rng.integers(0, 1 << 30)), ["natural", "highfreq", "flat"][int(rng.integers(0, 3))])
+                for _ in range(R)]
+        bind = rng.integers(0, R, P)
+        tests = [workloads.distort(refs[int(bind[k])], int(rng.integers(5, 100))) for k in range(P)]
+        b = ce.Batch(gpu_ctx, w, h, R, P)
+        for i, r in enumerate(refs):
+            b.set_reference(i, r)
+        for k in range(P):
+            b.set_test(k, int(bind[k]), tests[k])
+        want = []
+        for k in range(P):
+            r = refs[int(bind[k])]
+            want.append({"ssimulacra2": oracle.ssimulacra2(r, tests[k], w, h, 1), "dssim": oracle.dssim(r, tests[k], w, h),
+                         "butteraugli": oracle.butteraugli(r, tests[k], w, h)[0], "psnr": oracle.psnr(r, tests[k], w, h)})
+        for rep in range(2):
+            out = b.run(P, cfg)
+            for k in range(P):
+                assert out[k].psnr == want[k]["psnr"], (it, k)
+                for key, floor in (("ssimulacra2", 1.0), ("dssim", 1e-6), ("butteraugli", 1e-3)):
+                    rel = abs(getattr(out[k], key) - want[k][key]) / max(abs(want[k][key]), floor)
+                    assert rel <= 1e-6, (key, it, rep, w, h, R, P, k, getattr(out[k], key), want[k][key])
+        b.close()
+
+
 def test_irregular_pair_to_reference_bindings(gpu_ctx, ce, workloads):
     """The level-0 SSIMULACRA2 passes run from host-built XCD-aware work lists keyed by the pair -> reference table.
     Unsorted pairs, references with 0, 1 or many pairs, re-binding between runs: every pair must score exactly what
