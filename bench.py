@@ -24,6 +24,9 @@ import json
 import os
 import sys
 import time
+
+# before anything initialises HIP (torch does): see codec-eval_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -55,9 +58,11 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
     ap.add_argument("--one-context", action="store_true", help="all shape buckets on one context (buckets run back to back)")
     ap.add_argument("--all-events", action="store_true", help="events around every kernel in the timed region, not only level 0")
-    ap.add_argument("--solo", action="store_true", help="extra pass: time every kernel alone on one stream")
-    ap.add_argument("--depth", type=int, default=1,
-                    help="batches in flight per shape bucket (1 = launch and collect each step before the next)")
+    ap.add_argument("--solo", action="store_true", help="(default at N = 1) extra untimed pass: time every kernel alone on one stream")
+    ap.add_argument("--no-solo", action="store_true", help="skip the solo pass")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="batches in flight per shape bucket (1 = launch and collect each step before the next); "
+                         "default: 2 for configs 2 and 3, 1 for the mixed-metric configs 4 and 5 (measured)")
     return ap.parse_args()
 
 
@@ -129,9 +134,10 @@ def main():
     # One context (= one HIP stream family) per shape bucket, so the buckets' kernel chains overlap on the GPU.
     # `--depth` > 1 keeps that many sets of batches in flight (step k is launched before step k-1's scores are
     # collected, the way EvalSession streams a corpus larger than one batch); every timed step's scores are
-    # still collected inside the timed region.  Measured: no gain on this workload (the GPU is already busy),
-    # so the default is 1.
-    depth = max(1, args.depth)
+    # still collected inside the timed region.  Measured with 16 hardware queues: 21.5 k MP/s at depth 1, 22.2 k at
+    # depth 2 (the next step's front end fills the end of the previous step), no further gain at 3.  With HIP's default
+    # of 4 hardware queues depth 2 was SLOWER than depth 1: the extra streams queued behind busy ones.
+    depth = args.depth if args.depth > 0 else (2 if args.config in (2, 3) else 1)
     sets = []
     for _ in range(depth):
         cs = [ce.Context(local_rank) for _ in grids]
@@ -214,7 +220,7 @@ def main():
     for c in all_ctxs:
         c.prof_enable(False)
     solo = {}
-    if rank == 0 and args.solo:
+    if rank == 0 and (args.solo or (world == 1 and args.config == 2)) and not args.no_solo:
         # optional extra pass: one kernel at a time on one stream ("solo" durations, no sharing of the GPU)
         for c in ctxs:
             c.prof_reset()
@@ -294,8 +300,10 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": round(avg_s * 1e3, 4),
             "launches": launches,
-            "timing": "HIP events on the launch stream, in the timed region; kernels of other pyramid levels and of "
-                      "the other shape bucket run concurrently on other streams",
+            "timing": "HIP events on the launch stream, in the timed region; kernels of other pyramid levels, of the other "
+                      "shape bucket and of the next step run concurrently on other streams, so this duration is the "
+                      "share of the GPU the launch gets (solo_* = the same launch alone on the GPU; pipeline_* = all "
+                      "kernels of the step over the step time)",
             "dominant_by": "largest share of the step's algorithmic bytes (%.0f %%)" % (100.0 * alg_bytes.get(name, 0.0) / ssim2_step_bytes),
             "bytes_model": "12 B per blurred stream; a, a*a streams once per reference, the other three per pair; "
                            "an uncached pair would be %.0f B per launch" % (SSIM2_PASS_BYTES_L0 * px0 / n_launch_per_step),
@@ -377,6 +385,7 @@ def main():
                 "sharding": "by reference image, one process + one HIP stream per GPU, no collective",
                 "inputs": "resident in HBM (uploaded before the timed region)",
                 "batches_in_flight": depth,
+                "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

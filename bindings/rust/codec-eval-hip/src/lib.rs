@@ -74,6 +74,11 @@ unsafe impl Send for HipMetrics {}
 
 impl HipMetrics {
     pub fn new(device: i32) -> Result<Self, HipError> {
+        // HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); a sweep keeps more streams than
+        // that busy.  Read once, when the HIP runtime initialises - so this only helps before the first HIP call.
+        if std::env::var_os("GPU_MAX_HW_QUEUES").is_none() {
+            std::env::set_var("GPU_MAX_HW_QUEUES", "16");
+        }
         let mut ctx = ptr::null_mut();
         let rc = unsafe { sys::ce_ctx_create(device, &mut ctx) };
         if rc != sys::CE_OK {

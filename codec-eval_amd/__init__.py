@@ -18,6 +18,12 @@ from typing import Iterable, List, Optional, Sequence
 
 import numpy as np
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and a stream that shares a queue with a busy
+# one waits for it.  A context uses two streams per batch plus an upload stream, and callers keep several contexts /
+# batches in flight, so ask for 16 (read once, when the HIP runtime initialises: this only takes effect if the package
+# is imported before the process's first HIP call; 32 is far slower on MI355X, so it is a setdefault, not a maximum).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CE_METRICS_LIB") or os.path.join(_HERE, "libce_metrics_hip.so")
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")

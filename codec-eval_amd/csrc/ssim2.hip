@@ -829,10 +829,13 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     const int levels = std::min(b->n_scales, b->debug_max_scales);
     // Front end on the context's stream, level by level (level s+1 needs level s's linear planes).  Level 0's row
     // and column pass run on their own stream as soon as level 0's planes exist; levels 1.. share ONE row-pass and
-    // ONE column-pass launch on a second stream once the whole pyramid exists, so they overlap level 0.
+    // ONE column-pass launch that simply follow the front end on the context's stream, so they overlap level 0.
+    // Two streams per batch, not three: HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    // default) and a stream that shares a hardware queue with a busy one waits for it - with three streams per batch
+    // the second shape bucket's front end sat behind the first bucket's kernels for most of a step.
     // In the serial profiling mode everything stays on one stream so that per-kernel times do not overlap.
     hipStream_t s0 = ctx->prof_serial ? ctx->stream : b->lvl_stream[0];
-    hipStream_t s1 = ctx->prof_serial ? ctx->stream : b->lvl_stream[1];
+    hipStream_t s1 = ctx->stream;
     lvl_table tab{};
     lvl_table tab_v{};
     for (int s = 0; s < levels; s++) {
@@ -896,7 +899,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     }
     if (!ctx->prof_serial) {
         CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[0], 0));
-        if (tab.n) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[1], 0));
+        if (tab.n && s1 != ctx->stream) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[1], 0));
     }
     if (b->keep_ref_pyramid && !cached) {
         b->ssim2_ref_src = d_refs;
