@@ -897,7 +897,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                      0u, b->max_vblocks, rg, tab_v, (const uint2 *)b->d_work_vt, (const uint32_t *)b->d_pair_first);
         if (s1 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[1], s1));
     }
-    if (!ctx->prof_serial) {
+    if (s0 != ctx->stream) {
         CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[0], 0));
         if (tab.n && s1 != ctx->stream) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[1], 0));
     }
