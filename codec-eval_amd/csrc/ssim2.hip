@@ -154,17 +154,30 @@ __global__ __launch_bounds__(256) void k_ssim2_prep(const uint8_t *__restrict__ 
     float sum[3] = {0.0f, 0.0f, 0.0f};
     float *xo = xyb + (size_t)slot * 3 * plane;
 #pragma unroll
-    for (uint32_t dy = 0; dy < 2; dy++)
+    for (uint32_t dy = 0; dy < 2; dy++) {
+        const uint32_t yr = 2 * qy + dy, y = min(yr, h - 1);
+        float X[2], Y[2], B[2];
+        uint32_t lo = 0, hi = 0;  // the quad row's six bytes (two pixels), whatever their alignment
+        if (FROM_U8) {
+            // three aligned dwords around them instead of six byte loads (the slabs carry 16 bytes of padding)
+            const uintptr_t a = reinterpret_cast<uintptr_t>(src8 + ((size_t)y * w + 2 * qx) * 3);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], sh = (uint32_t)(a & 3);
+            lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            if (2 * qx + 1 >= w) {  // odd width: the second pixel is the first one again (clamped)
+                hi = (lo >> 8) & 0xffffu;
+                lo = (lo & 0x00ffffffu) | (lo << 24);
+            }
+        }
 #pragma unroll
         for (uint32_t dx = 0; dx < 2; dx++) {
-            const uint32_t xr = 2 * qx + dx, yr = 2 * qy + dy;
-            const uint32_t x = min(xr, w - 1), y = min(yr, h - 1);
+            const uint32_t xr = 2 * qx + dx, x = min(xr, w - 1);
             float r, g, bl;
             if (FROM_U8) {
-                const uint8_t *px = src8 + ((size_t)y * w + x) * 3;
-                r = s_lut[px[0]];
-                g = s_lut[px[1]];
-                bl = s_lut[px[2]];
+                r = s_lut[dx ? lo >> 24 : lo & 255u];
+                g = s_lut[dx ? hi & 255u : (lo >> 8) & 255u];
+                bl = s_lut[dx ? (hi >> 8) & 255u : (lo >> 16) & 255u];
             } else {
                 const size_t o = (size_t)y * pitch + x;
                 r = srcf[o];
@@ -174,15 +187,22 @@ __global__ __launch_bounds__(256) void k_ssim2_prep(const uint8_t *__restrict__ 
             sum[0] += r;
             sum[1] += g;
             sum[2] += bl;
-            if (xr < w && yr < h) {
-                float X, Y, B;
-                linear_to_xyb_positive(r, g, bl, cbrt_bias, X, Y, B);
-                const size_t o = (size_t)y * pitch + x;
-                xo[o] = X;
-                xo[o + plane] = Y;
-                xo[o + 2 * plane] = B;
+            linear_to_xyb_positive(r, g, bl, cbrt_bias, X[dx], Y[dx], B[dx]);
+        }
+        if (yr < h) {
+            // the quad's two pixels of a row leave as one 8-byte store per plane (2 qx is even, the pitch a multiple of 32)
+            const size_t o = (size_t)y * pitch + 2 * qx;
+            if (2 * qx + 1 < w) {
+                *reinterpret_cast<float2 *>(xo + o) = make_float2(X[0], X[1]);
+                *reinterpret_cast<float2 *>(xo + o + plane) = make_float2(Y[0], Y[1]);
+                *reinterpret_cast<float2 *>(xo + o + 2 * plane) = make_float2(B[0], B[1]);
+            } else {
+                xo[o] = X[0];
+                xo[o + plane] = Y[0];
+                xo[o + 2 * plane] = B[0];
             }
         }
+    }
     if (has_next) {
         float *lo = lin_out + (size_t)slot * 3 * oplane + (size_t)qy * opitch + qx;
         lo[0] = sum[0] * 0.25f;
