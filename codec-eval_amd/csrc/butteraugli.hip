@@ -307,6 +307,23 @@ __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ re
     if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
     const float *srcf = lin_in + (size_t)slot * 3 * g.plane;
     __syncthreads();
+    const bool interior = gx0 >= 0 && gy0 >= 0 && gx0 + FR <= w && gy0 + FR <= h;
+    if (FROM_U8 && interior) {
+        // four pixels (12 bytes, any alignment) per task from four aligned dwords; nine tasks per row of the region
+        for (int i = threadIdx.x; i < FR * (FR / 4); i += TPB) {
+            const int ly = i / (FR / 4), lx = 4 * (i % (FR / 4));
+            const uintptr_t a = reinterpret_cast<uintptr_t>(src8 + ((size_t)(gy0 + ly) * w + gx0 + lx) * 3);
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], sh = (uint32_t)(a & 3);
+            const uint32_t v0 = __builtin_amdgcn_alignbyte(d1, d0, sh), v1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                           v2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            const int o = ly * FR + lx;
+            L[0][o] = s_lut[v0 & 255u], L[1][o] = s_lut[(v0 >> 8) & 255u], L[2][o] = s_lut[(v0 >> 16) & 255u];
+            L[0][o + 1] = s_lut[v0 >> 24], L[1][o + 1] = s_lut[v1 & 255u], L[2][o + 1] = s_lut[(v1 >> 8) & 255u];
+            L[0][o + 2] = s_lut[(v1 >> 16) & 255u], L[1][o + 2] = s_lut[v1 >> 24], L[2][o + 2] = s_lut[v2 & 255u];
+            L[0][o + 3] = s_lut[(v2 >> 8) & 255u], L[1][o + 3] = s_lut[(v2 >> 16) & 255u], L[2][o + 3] = s_lut[v2 >> 24];
+        }
+    } else
     for (int i = threadIdx.x; i < FR * FR; i += TPB) {
         const int lx = i % FR, ly = i / FR, X = gx0 + lx, Y = gy0 + ly;
         if (X >= 0 && X < w && Y >= 0 && Y < h) {
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ re
             xyb[o + 2 * g.plane] = c2;
         }
     };
-    if (gx0 >= 0 && gy0 >= 0 && gx0 + FR <= w && gy0 + FR <= h)
+    if (interior)
         stages(std::true_type{});
     else
         stages(std::false_type{});
