@@ -592,10 +592,10 @@ __device__ constexpr mline MALTA_LF[16] = {
 
 constexpr int MT = 64, MH = 4, ML = MT + 2 * MH;  // 64x64 outputs per block from a zero-padded 72x72 LDS tile (1.27x halo)
 
-// ---- per pair, fused: the three Malta bands of one channel + that channel's L2 terms -----------------------------
-// For channel c in {X, Y}: UHF (9-sample lines), HF and MF (5-sample lines).  Per band the two images' 40x40
+// ---- per pair, fused: the three Malta bands of channels X and Y + every channel's L2 terms -----------------------
+// For channel c in {X, Y}: UHF (9-sample lines), HF and MF (5-sample lines).  Per band the two images' 72x72
 // regions are read once, the asymmetric pre-scaled difference (MaltaDiffMap's first loop) goes to LDS (zero outside
-// the image, as PaddedMaltaUnit does) and the 16 line sums are squared and accumulated in registers.  Then the
+// the image, as PaddedMaltaUnit does) and the 16 line sums are squared and accumulated.  Then the
 // L2DiffAsymmetric (HF), L2Diff (MF) and SetL2Diff (LF) terms of the channel are added and ac[c] / dc[c] are written
 // once.  Channel B has no Malta term: only L2Diff (MF) and SetL2Diff (LF).
 struct malta_bands {
@@ -625,122 +625,135 @@ __device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_
     return (lo || hi) ? (float)rn : r;
 }
 
-// The 16 line sums of MaltaUnit for FOUR horizontally adjacent centres, from a 9 x 12 register window
-// (27 16-byte LDS reads instead of 4 x 128 scalar ones).  Tap order per line as in the lineage.
+// Channels X and Y are PACKED: the LDS tile holds (x-diff, y-diff) pairs, a thread forms the 16 line sums of MaltaUnit
+// for two horizontally adjacent centres and both channels at once from a 9 x 10 register window of pairs (45 16-byte
+// LDS reads) on v_pk_add_f32 / v_pk_fma_f32 - two IEEE operations each, so every channel's sums are exactly those of a
+// scalar loop, tap order per line as in the lineage - and the block also writes channel B's L2 terms.
+// 72x72 float2 tile + 64x64 float2 running sums = 73 KB: two blocks per CU, 177 VGPRs.  (The scalar form - one channel
+// per block, four centres per thread - took 1.86 ms per four 4K pairs, this one 1.57 ms.)
 template <bool LF>
-__device__ __forceinline__ void malta_unit4(const float (&win)[9][12], float (&acc)[4])
+__device__ __forceinline__ void malta_unit2_xy(const ba_f2 (&win)[9][10], ba_f2 (&acc)[2])
 {
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-        float ret = 0.0f;
+    for (int o = 0; o < 2; o++) {
+        ba_f2 ret = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const mline &ln = LF ? MALTA_LF[k] : MALTA_HF[k];
-            float sum = 0.0f;
+            ba_f2 sum = {0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < 9; j++)
-                if (j < ln.n) sum += win[4 + ln.d[j][1]][4 + o + ln.d[j][0]];
-            ret = __builtin_fmaf(sum, sum, ret);
+                if (j < ln.n) sum = sum + win[4 + ln.d[j][1]][4 + o + ln.d[j][0]];
+            ret = __builtin_elementwise_fma(sum, sum, ret);
         }
-        acc[o] += ret;
+        acc[o] = acc[o] + ret;
     }
 }
 
-__global__ __launch_bounds__(TPB, 4) void k_ba_malta_l2(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
-                                                     float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
-                                                     uint32_t n_pairs_stride, malta_bands mb)
+__global__ __launch_bounds__(TPB, 2) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+                                                           float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
+                                                           uint32_t n_pairs_stride, malta_bands mb)
 {
-    __shared__ __attribute__((aligned(16))) float s[ML * ML];
-    __shared__ __attribute__((aligned(16))) float s_acc[MT * MT];  // the block's running sums; each thread owns its entries
-    const uint32_t p = blockIdx.z / 3, c = blockIdx.z % 3;
+    __shared__ __attribute__((aligned(16))) ba_f2 s[ML * ML];
+    __shared__ __attribute__((aligned(16))) ba_f2 s_acc[MT * MT];  // the block's running sums; each thread owns its entries
+    const uint32_t p = blockIdx.z;
     const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MT - MH;
     const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane;
     const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane;
-    // thread -> four adjacent outputs (columns 4*tq .. 4*tq+3 of row ty) in each of the tile's four 32x32 quadrants
-    const int tq = threadIdx.x & 7, ty = threadIdx.x >> 3;
-    if (c < 2) {
+    // thread -> two adjacent outputs (columns 2*tq, 2*tq+1 of row 8*sub + ty), eight row groups per tile
+    const int tq = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
-        for (int band = 0; band < 3; band++) {
-            const malta_params mp = mb.p[c][band];
-            const uint32_t band_plane = (band == 0 ? UHF0 : band == 1 ? HF0 : MF0) + c;
-            const float *pa = a + (size_t)band_plane * g.plane, *pb = b + (size_t)band_plane * g.plane;
-            // the tile starts 4 columns left of a 64-column boundary: every group of four is one aligned float4 of the row
-            for (int i = threadIdx.x; i < ML * (ML / 4); i += TPB) {
-                const int ly = i / (ML / 4), lq = i % (ML / 4), gx = x0 + 4 * lq, gy = y0 + ly;
-                float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-                const bool in = gx >= 0 && gy >= 0 && gx < (int)g.pitch && gy < (int)g.h;
-                if (in) {
-                    const size_t o = (size_t)gy * g.pitch + gx;
-                    va = *reinterpret_cast<const float4 *>(pa + o);
-                    vb = *reinterpret_cast<const float4 *>(pb + o);
-                }
-                float4 r;
-                r.x = (in && gx < (int)g.w) ? malta_pre_diff(va.x, vb.x, mp) : 0.0f;
-                r.y = (in && gx + 1 < (int)g.w) ? malta_pre_diff(va.y, vb.y, mp) : 0.0f;
-                r.z = (in && gx + 2 < (int)g.w) ? malta_pre_diff(va.z, vb.z, mp) : 0.0f;
-                r.w = (in && gx + 3 < (int)g.w) ? malta_pre_diff(va.w, vb.w, mp) : 0.0f;
-                *reinterpret_cast<float4 *>(s + ly * ML + 4 * lq) = r;
+    for (int band = 0; band < 3; band++) {
+        const malta_params mpx = mb.p[0][band], mpy = mb.p[1][band];
+        const uint32_t plane0 = band == 0 ? UHF0 : band == 1 ? HF0 : MF0;  // channel X's plane; channel Y's is the next one
+        const float *pax = a + (size_t)plane0 * g.plane, *pbx = b + (size_t)plane0 * g.plane;
+        const float *pay = pax + g.plane, *pby = pbx + g.plane;
+        for (int i = threadIdx.x; i < ML * (ML / 4); i += TPB) {
+            const int ly = i / (ML / 4), lq = i % (ML / 4), gx = x0 + 4 * lq, gy = y0 + ly;
+            float4 vax = make_float4(0.f, 0.f, 0.f, 0.f), vbx = vax, vay = vax, vby = vax;
+            const bool in = gx >= 0 && gy >= 0 && gx < (int)g.pitch && gy < (int)g.h;
+            if (in) {
+                const size_t o = (size_t)gy * g.pitch + gx;
+                vax = *reinterpret_cast<const float4 *>(pax + o);
+                vbx = *reinterpret_cast<const float4 *>(pbx + o);
+                vay = *reinterpret_cast<const float4 *>(pay + o);
+                vby = *reinterpret_cast<const float4 *>(pby + o);
             }
-            __syncthreads();
-#pragma unroll 1
-            for (int sub = 0; sub < 4; sub++) {
-                float4 *pacc = reinterpret_cast<float4 *>(s_acc + (32 * (sub >> 1) + ty) * MT + 32 * (sub & 1) + 4 * tq);
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};  // this band's sums; 0 + ret is exact, so adding them afterwards is the same sum
-                float win[9][12];
-#pragma unroll
-                for (int r = 0; r < 9; r++) {
-                    const float4 *row = reinterpret_cast<const float4 *>(s + (32 * (sub >> 1) + ty + r) * ML + 32 * (sub & 1) + 4 * tq);
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        const float4 v = row[q];
-                        win[r][4 * q] = v.x;
-                        win[r][4 * q + 1] = v.y;
-                        win[r][4 * q + 2] = v.z;
-                        win[r][4 * q + 3] = v.w;
-                    }
-                }
-                // block_diff_ac accumulates band by band in the lineage: same order here
-                if (band == 0)
-                    malta_unit4<false>(win, acc);
-                else
-                    malta_unit4<true>(win, acc);
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (band != 0) t = *pacc;
-                *pacc = make_float4(t.x + acc[0], t.y + acc[1], t.z + acc[2], t.w + acc[3]);
-            }
-            __syncthreads();
+            const bool i0 = in && gx < (int)g.w, i1 = in && gx + 1 < (int)g.w, i2 = in && gx + 2 < (int)g.w, i3 = in && gx + 3 < (int)g.w;
+            float4 r01, r23;  // (x0, y0, x1, y1), (x2, y2, x3, y3)
+            r01.x = i0 ? malta_pre_diff(vax.x, vbx.x, mpx) : 0.0f;
+            r01.y = i0 ? malta_pre_diff(vay.x, vby.x, mpy) : 0.0f;
+            r01.z = i1 ? malta_pre_diff(vax.y, vbx.y, mpx) : 0.0f;
+            r01.w = i1 ? malta_pre_diff(vay.y, vby.y, mpy) : 0.0f;
+            r23.x = i2 ? malta_pre_diff(vax.z, vbx.z, mpx) : 0.0f;
+            r23.y = i2 ? malta_pre_diff(vay.z, vby.z, mpy) : 0.0f;
+            r23.z = i3 ? malta_pre_diff(vax.w, vbx.w, mpx) : 0.0f;
+            r23.w = i3 ? malta_pre_diff(vay.w, vby.w, mpy) : 0.0f;
+            float4 *dst = reinterpret_cast<float4 *>(s + ly * ML + 4 * lq);
+            dst[0] = r01;
+            dst[1] = r23;
         }
+        __syncthreads();
+#pragma unroll 1
+        for (int sub = 0; sub < 8; sub++) {
+            ba_f2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};  // this band's sums; 0 + ret is exact, so adding them afterwards is the same sum
+            ba_f2 win[9][10];
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                const float4 *row = reinterpret_cast<const float4 *>(s + (8 * sub + ty + r) * ML + 2 * tq);
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    const float4 v = row[q];
+                    win[r][2 * q] = ba_f2{v.x, v.y};
+                    win[r][2 * q + 1] = ba_f2{v.z, v.w};
+                }
+            }
+            // block_diff_ac accumulates band by band in the lineage: same order here
+            if (band == 0)
+                malta_unit2_xy<false>(win, acc);
+            else
+                malta_unit2_xy<true>(win, acc);
+            float4 *pacc = reinterpret_cast<float4 *>(s_acc + (8 * sub + ty) * MT + 2 * tq);
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (band != 0) t = *pacc;
+            *pacc = make_float4(t.x + acc[0].x, t.y + acc[0].y, t.z + acc[1].x, t.w + acc[1].y);
+        }
+        __syncthreads();
     }
     const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
     const float hf_asymmetry = 1.0f;
 #pragma unroll 1
-    for (int sub = 0; sub < 4; sub++)
+    for (int sub = 0; sub < 8; sub++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t x = blockIdx.x * MT + 32 * (sub & 1) + 4 * tq + r, y = blockIdx.y * MT + 32 * (sub >> 1) + ty;
+    for (int r = 0; r < 2; r++) {
+        const uint32_t x = blockIdx.x * MT + 2 * tq + r, y = blockIdx.y * MT + 8 * sub + ty;
         if (x >= g.w || y >= g.h) continue;
         const size_t o = (size_t)y * g.pitch + x;
-        float total = c < 2 ? s_acc[(32 * (sub >> 1) + ty) * MT + 32 * (sub & 1) + 4 * tq + r] : 0.0f;
-        if (c < 2) {  // L2DiffAsymmetric on hf[c]
-            const float vw_0gt1 = wmul[c] * hf_asymmetry * 0.8f, vw_0lt1 = wmul[c] / hf_asymmetry * 0.8f;
-            const float val0 = a[(HF0 + c) * g.plane + o], val1 = b[(HF0 + c) * g.plane + o];
-            const float diff = val0 - val1;
-            total = __builtin_fmaf(diff * diff, vw_0gt1, total);
-            const float fabs0 = fabsf(val0);
-            const float too_small = 0.4f * fabs0, too_big = fabs0;
-            const float if_neg = val1 > -too_small ? val1 + too_small : (val1 < -too_big ? -val1 - too_big : 0.0f);
-            const float if_pos = val1 < too_small ? too_small - val1 : (val1 > too_big ? val1 - too_big : 0.0f);
-            const float v = val0 < 0.0f ? if_neg : if_pos;
-            total = __builtin_fmaf(vw_0lt1, v * v, total);
-        }
-        {  // L2Diff on mf[c]
-            const float diff = a[(MF0 + c) * g.plane + o] - b[(MF0 + c) * g.plane + o];
-            total = __builtin_fmaf(diff * diff, wmul[3 + c], total);
-        }
-        ac[((size_t)c * n_pairs_stride + p) * g.plane + o] = total;
-        {  // SetL2Diff on lf[c]
-            const float diff = a[(LF0 + c) * g.plane + o] - b[(LF0 + c) * g.plane + o];
-            dc[((size_t)c * n_pairs_stride + p) * g.plane + o] = (diff * diff) * wmul[6 + c];
+        const ba_f2 sums = s_acc[(8 * sub + ty) * MT + 2 * tq + r];
+#pragma unroll
+        for (uint32_t c = 0; c < 3; c++) {
+            float total = c == 0 ? sums.x : c == 1 ? sums.y : 0.0f;
+            if (c < 2) {  // L2DiffAsymmetric on hf[c]
+                const float vw_0gt1 = wmul[c] * hf_asymmetry * 0.8f, vw_0lt1 = wmul[c] / hf_asymmetry * 0.8f;
+                const float val0 = a[(HF0 + c) * g.plane + o], val1 = b[(HF0 + c) * g.plane + o];
+                const float diff = val0 - val1;
+                total = __builtin_fmaf(diff * diff, vw_0gt1, total);
+                const float fabs0 = fabsf(val0);
+                const float too_small = 0.4f * fabs0, too_big = fabs0;
+                const float if_neg = val1 > -too_small ? val1 + too_small : (val1 < -too_big ? -val1 - too_big : 0.0f);
+                const float if_pos = val1 < too_small ? too_small - val1 : (val1 > too_big ? val1 - too_big : 0.0f);
+                const float v = val0 < 0.0f ? if_neg : if_pos;
+                total = __builtin_fmaf(vw_0lt1, v * v, total);
+            }
+            {  // L2Diff on mf[c]
+                const float diff = a[(MF0 + c) * g.plane + o] - b[(MF0 + c) * g.plane + o];
+                total = __builtin_fmaf(diff * diff, wmul[3 + c], total);
+            }
+            ac[((size_t)c * n_pairs_stride + p) * g.plane + o] = total;
+            {  // SetL2Diff on lf[c]
+                const float diff = a[(LF0 + c) * g.plane + o] - b[(LF0 + c) * g.plane + o];
+                dc[((size_t)c * n_pairs_stride + p) * g.plane + o] = (diff * diff) * wmul[6 + c];
+            }
         }
     }
 }
@@ -1105,11 +1118,11 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         // ---- per pair ----
         float *ac = b->ba_pp[1], *dc = b->ba_pp[2], *m0 = b->ba_pp[3], *m1 = b->ba_pp[4],
               *bl0 = b->ba_pp[5], *bl1 = b->ba_pp[6], *tmp = b->ba_pp[7];
-        const dim3 mg((d.w + MT - 1) / MT, (d.h + MT - 1) / MT, n_pairs * 3);
+        const dim3 mg((d.w + MT - 1) / MT, (d.h + MT - 1) / MT, n_pairs);
         malta_bands mb;
         mb.p[0][0] = mUhfX; mb.p[0][1] = mHfX; mb.p[0][2] = mMfX;
         mb.p[1][0] = mUhfY; mb.p[1][1] = mHfY; mb.p[1][2] = mMfY;
-        CE_LAUNCH(ctx, "ba_malta_l2", k_ba_malta_l2, mg, dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P, mb);
+        CE_LAUNCH(ctx, "ba_malta_l2", k_ba_malta_l2_xy, mg, dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P, mb);
         // mask
         const plane_sel s1{1, 0, 1};
         CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m0, m1, g, mr);
