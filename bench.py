@@ -47,8 +47,8 @@ SSIM2_STREAM_BYTES = 12.0  # one blurred stream, three channels, f32
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="6 references instead of 24 (smoke runs)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
