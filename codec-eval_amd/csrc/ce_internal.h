@@ -101,8 +101,8 @@ struct ce_batch {
     float *d_lin[CE_MAX_SCALES] = {};  // [slots][3][plane_s] linear RGB pyramid
     float *d_xyb[CE_MAX_SCALES] = {};   // [slots][3][plane_s] positive XYB, one buffer per level
     float *d_hbuf[CE_MAX_SCALES] = {};  // [pairs][3][5][plane_s] row-blurred streams, one buffer per level
-    // the levels' row/column passes are independent once the front end has produced the level's XYB:
-    // each level runs on its own stream, fenced by events against the front end and the final reduction
+    // level 0's row/column pass runs on lvl_stream[0], fenced by events against the front end and the final reduction;
+    // the other levels follow the front end on the context's stream (entries 1.. are unused)
     hipStream_t lvl_stream[CE_MAX_SCALES] = {};
     // one stream per metric chain when a launch runs several of them (SSIMULACRA2, DSSIM, Butteraugli side by side)
     hipStream_t metric_stream[3] = {};

@@ -742,7 +742,7 @@ int ce_ssim2_prepare(ce_batch *b)
     for (int s = 0; s < ns; s++) {
         CE_HIP(ctx, hipMalloc(&b->d_xyb[s], slots * 3 * b->sd[s].plane * sizeof(float)));
         CE_HIP(ctx, hipMalloc(&b->d_hbuf[s], (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[s].plane * sizeof(float)));
-        CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[s], hipStreamNonBlocking));
+        if (s == 0) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[0], hipStreamNonBlocking));  // level 0's passes; the other levels follow the front end
         CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_prep[s], hipEventDisableTiming));
         CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
     }
