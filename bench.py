@@ -185,6 +185,12 @@ def main():
         c.prof_filter("" if args.all_events else "_L0")
         c.prof_enable(events, serial=False)
 
+    # one untimed pass over every set of batches first: lazy device allocations and the host-built work lists are part
+    # of setting a batch up, not of a step (with --depth 2 a short warm-up would otherwise leave the second set cold)
+    for _, bs in sets:
+        for g, b in bs:
+            b.launch(len(g.pairs), cfg)
+            b.collect(len(g.pairs))
     run_steps(args.warmup)
     for c in all_ctxs:
         c.prof_reset()
