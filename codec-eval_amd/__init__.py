@@ -120,6 +120,8 @@ _PROTOTYPES = [
     ("ce_rgb8_to_dssim_image", _i, [_vp, _u8p, _sz, _sz, _sz, _vp]),
     ("ce_eval_pair", _i, [_vp, _u8p, _sz, _u8p, _sz, _u32, _u32, _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_eval_batch", _i, [_vp, _sz, C.POINTER(CePairDesc), _u32, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_estimate_batch_bytes", _sz, [_u32, _u32, _u32, _u32, _u32]),
+    ("ce_ctx_memory_info", _i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     ("ce_batch_create", _i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("ce_batch_destroy", None, [_vp]),
     ("ce_batch_set_reference", _i, [_vp, _u32, _u8p, _sz]),
@@ -168,6 +170,11 @@ def lib() -> C.CDLL:
             fn.restype = restype
             fn.argtypes = argtypes
     return _lib
+
+
+def estimate_batch_bytes(width: int, height: int, n_refs: int, n_pairs: int, config: "MetricConfig") -> int:
+    """Upper estimate of the device bytes a Batch of this shape holds once `config`'s metrics have run."""
+    return int(lib().ce_estimate_batch_bytes(width, height, n_refs, n_pairs, config.mask))
 
 
 def version() -> str:
@@ -320,6 +327,12 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ce_ctx_synchronize(self._h))
+
+    def memory_info(self):
+        """(free, total) device bytes."""
+        free, total = C.c_size_t(), C.c_size_t()
+        self._check(lib().ce_ctx_memory_info(self._h, C.byref(free), C.byref(total)))
+        return free.value, total.value
 
     def debug_cbrt_sweep(self, first_bits: int, count: int):
         """(mismatches, fallbacks) of the fast vs reference cube root over f32 bit patterns."""

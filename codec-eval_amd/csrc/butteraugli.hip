@@ -1022,9 +1022,8 @@ void ce_butteraugli_free(ce_batch *b)
     b->ba_ready = false;
 }
 
-static int ba_prepare(ce_batch *b)
+static int ba_allocate(ce_batch *b)
 {
-    if (b->ba_ready) return CE_OK;
     ce_ctx *ctx = b->ctx;
     auto set = [](ce_batch::ba_level &d, uint32_t w, uint32_t h) {
         d.w = w;
@@ -1049,6 +1048,20 @@ static int ba_prepare(ce_batch *b)
     CE_HIP(ctx, hipMalloc(&b->ba_blk_max, P * b->ba_blocks * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ba_blk_sums, P * b->ba_blocks * 3 * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->ba_pnorm, P * sizeof(double)));
+    return CE_OK;
+}
+
+static int ba_prepare(ce_batch *b)
+{
+    if (b->ba_ready) return CE_OK;
+    const int rc = ba_allocate(b);
+    if (rc != CE_OK) {  // all or nothing (see ce_ssim2_prepare)
+        const std::string why = b->ctx->err;
+        ce_butteraugli_free(b);
+        (void)hipGetLastError();
+        b->ctx->err = why;
+        return rc;
+    }
     b->ba_ready = true;
     return CE_OK;
 }

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <thread>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -76,6 +77,7 @@ void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream) { hipEventRecord(ct
 static void prof_drain(ce_ctx *ctx)
 {
     if (ctx->pend.empty()) return;
+    hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &pd : ctx->pend) {
         float ms = 0.f;
@@ -172,6 +174,7 @@ void ce_ctx_destroy(ce_ctx *ctx)
 int ce_ctx_synchronize(ce_ctx *ctx)
 {
     if (!ctx) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CE_OK;
 }
@@ -248,22 +251,15 @@ void ce_batch_destroy(ce_batch *b)
         if (b->h_stage[k]) hipHostFree(b->h_stage[k]);
         if (b->ev_stage[k]) hipEventDestroy(b->ev_stage[k]);
     }
-    for (auto &p : b->d_lin) hipFree(p);
-    for (int l = 0; l < CE_MAX_SCALES; l++) {
-        hipFree(b->d_xyb[l]);
-        hipFree(b->d_hbuf[l]);
-        if (b->lvl_stream[l]) hipStreamSynchronize(b->lvl_stream[l]), hipStreamDestroy(b->lvl_stream[l]);
-        if (l < 3 && b->metric_stream[l]) hipStreamSynchronize(b->metric_stream[l]), hipStreamDestroy(b->metric_stream[l]);
-        if (l < 3 && b->ev_join[l]) hipEventDestroy(b->ev_join[l]);
-        if (b->ev_prep[l]) hipEventDestroy(b->ev_prep[l]);
-        if (b->ev_done[l]) hipEventDestroy(b->ev_done[l]);
+    for (int l = 0; l < 3; l++) {
+        if (b->metric_stream[l]) hipStreamSynchronize(b->metric_stream[l]), hipStreamDestroy(b->metric_stream[l]);
+        if (b->ev_join[l]) hipEventDestroy(b->ev_join[l]);
     }
+    ce_ssim2_free(b);
     hipFree(b->d_work_h);
     hipFree(b->d_work_v);
     hipFree(b->d_work_ht);
     hipFree(b->d_work_vt);
-    hipFree(b->d_partials);
-    hipFree(b->d_avg);
     ce_dssim_free(b);
     ce_butteraugli_free(b);
     delete b;
@@ -275,6 +271,7 @@ static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src)
     // pageable source -> pinned staging ring -> device on the batch's upload stream.  The caller's buffer is
     // consumed before this returns; the DMA of this slot overlaps the host copy into the next one and the
     // kernels of other batches.  A launched-but-uncollected run of THIS batch still reads the slabs: wait for it.
+    CE_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread's current device may be another one (multi-device hosts)
     if (b->run_pending) {
         CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
         b->run_pending = false;  // ordered from here on
@@ -324,6 +321,7 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
 {
     ce_ctx *ctx = b->ctx;
     if (jobs.empty()) return CE_OK;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     // Page-locked sources skip the staging ring: one asynchronous copy per image straight from the caller's buffer.
     // Only ce_eval_batch comes through here, and it collects (synchronises) before it returns, so the buffers
     // outlive the copies.
@@ -415,6 +413,7 @@ static int upload_fmt(ce_batch *b, uint8_t *dst, const void *pixels, size_t len,
         return fail(ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(n_px * bpp) + " bytes, got " +
                                                 std::to_string(len));
     if (format == CE_PIXEL_RGB8) return upload(b, dst, static_cast<const uint8_t *>(pixels));
+    CE_HIP(ctx, hipSetDevice(ctx->device));  // the staging allocations and the ingest launch below go to the context's device
     if (!b->h_wide) {
         CE_HIP(ctx, hipHostMalloc(&b->h_wide, n_px * 8, hipHostMallocDefault));
         CE_HIP(ctx, hipMalloc(&b->d_wide, n_px * 8));
@@ -578,6 +577,7 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
     if (!b || !out) return CE_ERR_INVALID_ARG;
     ce_ctx *ctx = b->ctx;
     if (n_pairs == 0 || n_pairs > b->max_pairs) return fail(ctx, CE_ERR_INVALID_ARG, "n_pairs out of range");
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipMemcpyAsync(b->h_scores, b->d_scores, sizeof(ce_dev_scores) * n_pairs, hipMemcpyDeviceToHost,
                                ctx->stream));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -620,6 +620,7 @@ int ce_batch_butteraugli_pnorm3(ce_batch *b, uint32_t n_pairs, double *out)
 {
     if (!b || !out || !b->ba_ready || n_pairs == 0 || n_pairs > b->max_pairs) return CE_ERR_INVALID_ARG;
     ce_ctx *ctx = b->ctx;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     CE_HIP(ctx, hipMemcpy(out, b->ba_pnorm, sizeof(double) * n_pairs, hipMemcpyDeviceToHost));
     return CE_OK;
@@ -635,6 +636,63 @@ int ce_batch_run(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t f
 
 // ---- single pair / mixed batch ----------------------------------------------------------------
 
+// Device bytes a batch of this shape needs once the metrics in `mask` have run (working sets are allocated lazily,
+// per metric).  Mirrors ce_ssim2_prepare / dssim_prepare / ba_prepare, with the plane padding folded into one factor.
+size_t ce_estimate_batch_bytes(uint32_t w, uint32_t h, uint32_t n_refs, uint32_t n_pairs, uint32_t metric_mask)
+{
+    const double px = (double)w * h, slots = (double)n_refs + n_pairs, pairs = n_pairs;
+    double bytes = 3.0 * px * slots + 64.0 * pairs;  // u8 slabs, scores
+    if (metric_mask & CE_METRIC_SSIMULACRA2)  // linear pyramid (levels >= 1) 4, XYB pyramid 16 per slot; 15 row-blurred planes x 1.333 per pair
+        bytes += px * (20.0 * slots + 80.0 * pairs);
+    if (metric_mask & CE_METRIC_DSSIM)  // linear ping-pong 6, img / mu / sq 36 per slot; SSIM map 4 per pair
+        bytes += px * (42.0 * slots + 4.0 * pairs);
+    if (metric_mask & CE_METRIC_BUTTERAUGLI)  // half-res linear 3, PsychoImage 50, three 3-plane scratch sets 36 per slot; diffmaps 5 + 12 scratch planes per pair
+        bytes += px * (89.0 * slots + 53.0 * pairs);
+    if (metric_mask & CE_METRIC_PSNR) bytes += 8.0 * pairs;
+    return (size_t)(bytes * 1.2) + (8u << 20);  // row / pitch padding of the planar buffers, staging ring
+}
+
+int ce_ctx_memory_info(ce_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!ctx || !free_bytes || !total_bytes) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    CE_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return CE_OK;
+}
+
+// bytes one ce_eval_batch chunk may allocate: CE_EVAL_BATCH_BYTES if set (tests), else a share of what is free now
+static size_t chunk_budget(ce_ctx *ctx)
+{
+    if (const char *e = std::getenv("CE_EVAL_BATCH_BYTES")) {
+        const long long v = std::atoll(e);
+        if (v > 0) return (size_t)v;
+    }
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t)8 << 30;
+    // the pooled batches of this context are reused, so what they hold already counts as available
+    size_t pooled = 0;
+    for (auto &kv : ctx->shape_pool) {
+        const ce_batch *pb = kv.second;
+        const uint32_t held = (pb->ssim2_ready ? CE_METRIC_SSIMULACRA2 : 0u) | (pb->dssim_ready ? CE_METRIC_DSSIM : 0u) |
+                              (pb->ba_ready ? CE_METRIC_BUTTERAUGLI : 0u);
+        pooled += ce_estimate_batch_bytes(pb->w, pb->h, pb->max_refs, pb->max_pairs, held);
+    }
+    return (size_t)((double)(free_b + pooled) * 0.8 / ce_ctx::kPoolRing);
+}
+
+// free every pooled batch that has nothing in flight (called when a new one does not fit)
+static void pool_evict_idle(ce_ctx *ctx)
+{
+    for (auto it = ctx->shape_pool.begin(); it != ctx->shape_pool.end();) {
+        if (!it->second->run_pending && !it->second->uploads_pending) {
+            ce_batch_destroy(it->second);
+            it = ctx->shape_pool.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 static int shape_batch(ce_ctx *ctx, uint32_t w, uint32_t h, uint32_t need_pairs, uint32_t ring_slot, ce_batch **out)
 {
     auto key = std::make_tuple(w, h, ring_slot);
@@ -649,6 +707,10 @@ static int shape_batch(ce_ctx *ctx, uint32_t w, uint32_t h, uint32_t need_pairs,
     }
     ce_batch *b = nullptr;
     int rc = ce_batch_create(ctx, w, h, need_pairs, need_pairs, &b);
+    if (rc == CE_ERR_BACKEND) {  // out of device memory: drop the idle pooled batches of other shapes / sizes and retry once
+        pool_evict_idle(ctx);
+        rc = ce_batch_create(ctx, w, h, need_pairs, need_pairs, &b);
+    }
     if (rc != CE_OK) return rc;
     ctx->shape_pool[key] = b;
     *out = b;
@@ -699,7 +761,20 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
             }
         }
         const size_t n_chunks = std::min<size_t>(ce_ctx::kPoolRing, std::max<size_t>(1, idx.size() / 16));
-        const size_t target = (idx.size() + n_chunks - 1) / n_chunks;
+        size_t target = (idx.size() + n_chunks - 1) / n_chunks;
+        // ... and a chunk must fit the device: cap the pairs per chunk by bytes per pair (every pair budgeted with a
+        // reference of its own) against a share of the free memory; a grid larger than that streams through the ring
+        // in more chunks.  A reference with more tests than the cap is split (its reference is uploaded once per part).
+        {
+            const size_t per_pair = ce_estimate_batch_bytes(kv.first.first, kv.first.second, 1, 1, metric_mask) - (8u << 20);
+            const size_t cap = std::max<size_t>(1, chunk_budget(ctx) / std::max<size_t>(per_pair, 1));
+            target = std::min(target, cap);
+            std::vector<std::vector<size_t>> split;
+            for (auto &g : groups)
+                for (size_t o = 0; o < g.size(); o += target)
+                    split.emplace_back(g.begin() + o, g.begin() + std::min(g.size(), o + target));
+            groups.swap(split);
+        }
         size_t g0 = 0;
         while (g0 < groups.size()) {
             size_t g1 = g0, count = 0;
@@ -891,6 +966,7 @@ int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *
     if (n_tests == 0) return CE_OK;
     ce_ctx *ctx = ref->ctx;
     ce_batch *b = ref->batch;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     if (n_tests > b->max_pairs) {
         // grow the handle: a new batch of the same shape takes over the resident reference (device copy)
         ce_batch *nb = nullptr;
@@ -997,6 +1073,7 @@ int ce_prof_get(ce_ctx *ctx, int index, const char **name, uint64_t *launches, d
 int ce_timer_start(ce_ctx *ctx)
 {
     if (!ctx) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
     return CE_OK;
 }
@@ -1004,6 +1081,7 @@ int ce_timer_start(ce_ctx *ctx)
 int ce_timer_stop(ce_ctx *ctx, double *elapsed_ms)
 {
     if (!ctx || !elapsed_ms) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
     CE_HIP(ctx, hipEventSynchronize(ctx->t1));
     float ms = 0.f;
@@ -1038,6 +1116,7 @@ int ce_debug_ssim2_planes(ce_batch *b, int scale, int which, int channel, float 
             break;
         default: return CE_ERR_INVALID_ARG;
     }
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t spl = which == 4 ? d.hplane : d.plane, spitch = which == 4 ? d.hpitch : d.pitch;
     for (int p = 0; p < nplanes; p++)
@@ -1059,6 +1138,7 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg, int *
 {
     if (!b || !avg || !b->ssim2_ready || pair_index >= b->max_pairs) return CE_ERR_INVALID_ARG;
     ce_ctx *ctx = b->ctx;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     CE_HIP(ctx, hipMemcpy(avg, b->d_avg + (size_t)pair_index * CE_MAX_SCALES * 18, sizeof(double) * CE_MAX_SCALES * 18,
                           hipMemcpyDeviceToHost));
@@ -1071,6 +1151,7 @@ int ce_debug_ssim2_occupancy(int which) { return ce_ssim2_occupancy(which); }
 int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path)
 {
     if (!ctx || count == 0 || (uint64_t)first_bits + count > (1ull << 32)) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
     return ce_ssim2_cbrt_sweep(ctx, first_bits, count, mismatches, slow_path);
 }
 

@@ -191,6 +191,7 @@ int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);
 size_t ce_pixel_bytes(int format);
 int ce_launch_ingest(ce_ctx *ctx, hipStream_t stream, int format, const void *d_src, uint8_t *d_dst, size_t n_pixels);
 int ce_ssim2_prepare(ce_batch *b);
+void ce_ssim2_free(ce_batch *b);
 int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);
 int ce_ssim2_occupancy(int which);
 int ce_ssim2_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path);

@@ -407,9 +407,8 @@ void ce_dssim_free(ce_batch *b)
     b->dssim_ready = false;
 }
 
-static int dssim_prepare(ce_batch *b)
+static int dssim_allocate(ce_batch *b)
 {
-    if (b->dssim_ready) return CE_OK;
     ce_ctx *ctx = b->ctx;
     uint32_t w = b->w, h = b->h;
     int n = 0;
@@ -439,6 +438,20 @@ static int dssim_prepare(ce_batch *b)
     b->ds_blocks = ((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->ds_level_scores, (size_t)b->max_pairs * CE_DSSIM_SCALES * sizeof(double)));  // avg, then score
+    return CE_OK;
+}
+
+static int dssim_prepare(ce_batch *b)
+{
+    if (b->dssim_ready) return CE_OK;
+    const int rc = dssim_allocate(b);
+    if (rc != CE_OK) {  // all or nothing (see ce_ssim2_prepare)
+        const std::string why = b->ctx->err;
+        ce_dssim_free(b);
+        (void)hipGetLastError();
+        b->ctx->err = why;
+        return rc;
+    }
     b->dssim_ready = true;
     return CE_OK;
 }

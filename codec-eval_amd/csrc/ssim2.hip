@@ -711,10 +711,49 @@ __global__ __launch_bounds__(128) void k_ssim2_finalize(const double *__restrict
 
 // ---- host side ---------------------------------------------------------------------------
 
+void ce_ssim2_free(ce_batch *b)
+{
+    for (int s = 0; s < CE_MAX_SCALES; s++) {
+        hipFree(b->d_lin[s]);
+        hipFree(b->d_xyb[s]);
+        hipFree(b->d_hbuf[s]);
+        b->d_lin[s] = b->d_xyb[s] = b->d_hbuf[s] = nullptr;
+        if (b->lvl_stream[s]) hipStreamSynchronize(b->lvl_stream[s]), hipStreamDestroy(b->lvl_stream[s]);
+        if (b->ev_prep[s]) hipEventDestroy(b->ev_prep[s]);
+        if (b->ev_done[s]) hipEventDestroy(b->ev_done[s]);
+        b->lvl_stream[s] = nullptr;
+        b->ev_prep[s] = b->ev_done[s] = nullptr;
+    }
+    hipFree(b->d_partials);
+    hipFree(b->d_avg);
+    b->d_partials = nullptr;
+    b->d_avg = nullptr;
+    b->ssim2_ready = false;
+}
+
+static int ssim2_allocate(ce_batch *b)
+{
+    ce_ctx *ctx = b->ctx;
+    const int ns = b->n_scales;
+    const size_t slots = (size_t)b->max_refs + b->max_pairs;
+    for (int s = 1; s < ns; s++)  // level 0 is read straight from the u8 slabs
+        CE_HIP(ctx, hipMalloc(&b->d_lin[s], slots * 3 * b->sd[s].plane * sizeof(float)));
+    for (int s = 0; s < ns; s++) {
+        CE_HIP(ctx, hipMalloc(&b->d_xyb[s], slots * 3 * b->sd[s].plane * sizeof(float)));
+        CE_HIP(ctx, hipMalloc(&b->d_hbuf[s], (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[s].plane * sizeof(float)));
+        if (s == 0) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[0], hipStreamNonBlocking));  // level 0's passes; the other levels follow the front end
+        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_prep[s], hipEventDisableTiming));
+        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
+    }
+    b->max_vblocks = (b->sd[0].w + kColsPerBlock - 1) / kColsPerBlock;
+    CE_HIP(ctx, hipMalloc(&b->d_partials, (size_t)b->max_pairs * CE_MAX_SCALES * 3 * b->max_vblocks * 6 * sizeof(double)));
+    CE_HIP(ctx, hipMalloc(&b->d_avg, (size_t)b->max_pairs * CE_MAX_SCALES * 18 * sizeof(double)));
+    return CE_OK;
+}
+
 int ce_ssim2_prepare(ce_batch *b)
 {
     if (b->ssim2_ready) return CE_OK;
-    ce_ctx *ctx = b->ctx;
     uint32_t w = b->w, h = b->h;
     int ns = 0;
     // The lineage tests the size BEFORE halving (`if w < 8 || h < 8 {break}; if scale > 0
@@ -736,19 +775,16 @@ int ce_ssim2_prepare(ce_batch *b)
     }
     b->n_scales = ns;
     if (ns == 0) return CE_OK;
-    const size_t slots = (size_t)b->max_refs + b->max_pairs;
-    for (int s = 1; s < ns; s++)  // level 0 is read straight from the u8 slabs
-        CE_HIP(ctx, hipMalloc(&b->d_lin[s], slots * 3 * b->sd[s].plane * sizeof(float)));
-    for (int s = 0; s < ns; s++) {
-        CE_HIP(ctx, hipMalloc(&b->d_xyb[s], slots * 3 * b->sd[s].plane * sizeof(float)));
-        CE_HIP(ctx, hipMalloc(&b->d_hbuf[s], (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[s].plane * sizeof(float)));
-        if (s == 0) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[0], hipStreamNonBlocking));  // level 0's passes; the other levels follow the front end
-        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_prep[s], hipEventDisableTiming));
-        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
+    // all or nothing: a partial working set (an allocation failed half-way) is released, so that a retry
+    // after the caller has made room starts clean instead of overwriting live pointers
+    const int rc = ssim2_allocate(b);
+    if (rc != CE_OK) {
+        const std::string why = b->ctx->err;
+        ce_ssim2_free(b);
+        (void)hipGetLastError();
+        b->ctx->err = why;
+        return rc;
     }
-    b->max_vblocks = (b->sd[0].w + kColsPerBlock - 1) / kColsPerBlock;
-    CE_HIP(ctx, hipMalloc(&b->d_partials, (size_t)b->max_pairs * CE_MAX_SCALES * 3 * b->max_vblocks * 6 * sizeof(double)));
-    CE_HIP(ctx, hipMalloc(&b->d_avg, (size_t)b->max_pairs * CE_MAX_SCALES * 18 * sizeof(double)));
     b->ssim2_ready = true;
     return CE_OK;
 }

@@ -4,10 +4,11 @@
 // u8-exactness against the reference's arithmetic (which calls the HOST libm for powf/cbrtf):
 //   * sRGB->linear (xyb.rs:60-66,80-82): only 256 inputs exist -> table built by the host with
 //     the host's powf (ce_tables.cpp), read from LDS.
-//   * cbrt (xyb.rs:92-94): glibc's cbrtf is a frexp / quadratic seed / one Halley step in
-//     double / ldexp routine.  It is restated below with IEEE basic operations only, so the
-//     device reproduces it bit for bit (tests/test_xyb.py checks the restatement against the
-//     host cbrtf, and the full 2^24-colour cube against the CPU oracle).
+//   * cbrt (xyb.rs:92-94): PINNED to glibc 2.35's cbrtf (frexp / quadratic seed / one Halley step in
+//     double / ldexp), restated below with IEEE basic operations only.  The oracle runs the same
+//     restatement (ceo_cbrtf_pinned, oracle/psnr_xyb.c), so device == oracle on any host whatever its
+//     libm; tests/test_oracle_pinning.py::test_xyb_cbrtf_is_pinned_in_one_place compares the pin with
+//     the host's cbrtf, tests/test_gpu_parity.py checks the full 2^24-colour cube against the oracle.
 //   * linear->sRGB u8 (xyb.rs:70-76,86-88): round(255*(1.055*powf(c,1/2.4)-0.055)) is a
 //     monotone step function of the clamped f32 input, so it is decided by 255 thresholds
 //     that the host finds with its own powf (ce_tables.cpp); the device only compares.

@@ -9,6 +9,7 @@ reference's loop order.  Report types and writers are in `reports.py`.
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -16,7 +17,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import (PIXEL_RGB8, PIXEL_RGBA8, Batch, CodecEvalError, Context, DimensionMismatch, MetricCalculation,
-               MetricConfig, MetricResult, _error_obj, CE_ERR_BACKEND)
+               MetricConfig, MetricResult, _error_obj, estimate_batch_bytes, CE_ERR_BACKEND)
 from . import reports as R
 
 __all__ = ["ImageData", "EncodeRequest", "EvalConfig", "EvalConfigBuilder", "EvalSession"]
@@ -189,30 +190,53 @@ class EvalSession:
             if pending:
                 buckets.setdefault((image.width, image.height), []).append((image, report, pending))
         for (w, h), group in buckets.items():
-            n_refs = len(group)
-            n_pairs = sum(len(p) for _, _, p in group)
-            batch = Batch(self.ctx, w, h, n_refs, n_pairs)
-            try:
-                rows = []
-                k = 0
-                for ri, (image, report, pending) in enumerate(group):
-                    batch.set_reference_fmt(ri, image.data, image.pixel_format)
-                    for row_index, decoded in pending:
-                        if (decoded.width, decoded.height) != (w, h):  # calculate_metrics' length check, ssimulacra2.rs:65-70
-                            raise DimensionMismatch(1, f"Dimension mismatch: expected ({w}, {h}), got ({decoded.width}, {decoded.height})")
-                        batch.set_test_fmt(k, ri, decoded.data, decoded.pixel_format)
-                        rows.append((report, row_index))
-                        k += 1
-                scores = batch.run(n_pairs, cfg)
-            finally:
-                batch.close()
-            for (report, row_index), s in zip(rows, scores):
-                if s.status != 0:
-                    raise _error_obj(s.status, self.ctx._err())
-                m = MetricResult.from_c(s)
-                row = report.results[row_index]
-                row.dssim, row.ssimulacra2, row.butteraugli, row.psnr = m.dssim, m.ssimulacra2, m.butteraugli, m.psnr
-                row.perception = m.perception_level()  # session.rs:407
+            # a shape's cells go through device batches that fit the device: whole images while they fit, an image with
+            # more cells than one batch holds is split (its reference is uploaded once per part)
+            free, _total = self.ctx.memory_info()
+            budget = int(os.environ.get("CE_SESSION_BATCH_BYTES", 0)) or int(free * 0.6)
+            fixed = estimate_batch_bytes(w, h, 0, 0, cfg)
+            per_ref = estimate_batch_bytes(w, h, 1, 0, cfg) - fixed
+            per_pair = estimate_batch_bytes(w, h, 0, 1, cfg) - fixed
+            max_pairs = max(1, (budget - fixed - per_ref) // max(per_pair, 1))
+            parts: List[list] = [[]]  # each part: [(image, report, cells)]
+            used = fixed
+            for image, report, pending in group:
+                for o in range(0, len(pending), max_pairs):
+                    cells = pending[o:o + max_pairs]
+                    need = per_ref + per_pair * len(cells)
+                    if parts[-1] and used + need > budget:
+                        parts.append([])
+                        used = fixed
+                    parts[-1].append((image, report, cells))
+                    used += need
+            for part in parts:
+                self._score_part(w, h, part, cfg)
+
+    def _score_part(self, w: int, h: int, group, cfg: MetricConfig):
+        n_refs = len(group)
+        n_pairs = sum(len(p) for _, _, p in group)
+        batch = Batch(self.ctx, w, h, n_refs, n_pairs)
+        try:
+            rows = []
+            k = 0
+            for ri, (image, report, pending) in enumerate(group):
+                batch.set_reference_fmt(ri, image.data, image.pixel_format)
+                for row_index, decoded in pending:
+                    if (decoded.width, decoded.height) != (w, h):  # calculate_metrics' length check, ssimulacra2.rs:65-70
+                        raise DimensionMismatch(1, f"Dimension mismatch: expected ({w}, {h}), got ({decoded.width}, {decoded.height})")
+                    batch.set_test_fmt(k, ri, decoded.data, decoded.pixel_format)
+                    rows.append((report, row_index))
+                    k += 1
+            scores = batch.run(n_pairs, cfg)
+        finally:
+            batch.close()
+        for (report, row_index), s in zip(rows, scores):
+            if s.status != 0:
+                raise _error_obj(s.status, self.ctx._err())
+            m = MetricResult.from_c(s)
+            row = report.results[row_index]
+            row.dssim, row.ssimulacra2, row.butteraugli, row.psnr = m.dssim, m.ssimulacra2, m.butteraugli, m.psnr
+            row.perception = m.perception_level()  # session.rs:407
 
     def evaluate_image(self, name: str, image: ImageData) -> R.ImageReport:  # session.rs:368-434
         image._check_profile()

@@ -134,6 +134,13 @@ int ce_eval_pair(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, co
 int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t metric_mask, uint32_t flags,
                   float intensity_target, ce_scores *out);
 
+/* Memory planning for callers that size their own batches (EvalSession::evaluate_corpus streams a corpus through
+ * batches that fit the device): an upper estimate of the device bytes a batch of this shape holds once the metrics
+ * in metric_mask have run, and the device's free / total memory.  ce_eval_batch uses the same estimate to split a
+ * grid that does not fit into chunks (each at most a third of the free memory; CE_EVAL_BATCH_BYTES overrides). */
+size_t ce_estimate_batch_bytes(uint32_t width, uint32_t height, uint32_t n_refs, uint32_t n_pairs, uint32_t metric_mask);
+int ce_ctx_memory_info(ce_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+
 /* ---- HBM-resident grid (what bench.py times; inputs already on device) ---------- */
 /* One shape, up to max_refs reference images and max_pairs (reference, test) items. */
 int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_refs, uint32_t max_pairs,

@@ -56,6 +56,9 @@ float ceo_srgb_u8_to_linear(uint8_t v);
 void ceo_rgb8_to_dssim_image(const uint8_t *rgb, size_t npix, float *rgba_out);
 
 /* ---- XYB roundtrip: src/metrics/xyb.rs:225-253 -------------------------- */
+/* the pinned cube root of the roundtrip (glibc 2.35's cbrtf restated; psnr_xyb.c) and the host's, n values each */
+float ceo_cbrtf_pinned(float x);
+void ceo_cbrtf_compare(const float *x, size_t n, float *pinned, float *host);
 int ceo_xyb_roundtrip(const uint8_t *rgb, size_t len, size_t width, size_t height, uint8_t *out);
 
 /* ---- SSIMULACRA2: ssimulacra2.rs:59-100 -> fast-ssim2 ------------------- */

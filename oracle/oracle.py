@@ -44,6 +44,8 @@ def lib() -> C.CDLL:
         _lib.ceo_rgb8_to_dssim_image.argtypes = [u8p, sz, f32p]
         _lib.ceo_rgb8_to_dssim_image.restype = None
         _lib.ceo_xyb_roundtrip.argtypes = [u8p, sz, sz, sz, u8p]
+        _lib.ceo_cbrtf_compare.argtypes = [f32p, sz, f32p, f32p]
+        _lib.ceo_cbrtf_compare.restype = None
         _lib.ceo_ssimulacra2.argtypes = [u8p, sz, u8p, sz, sz, sz, C.c_int, f64p]
         _lib.ceo_ssimulacra2_detail.argtypes = [u8p, u8p, sz, sz, C.c_int, f64p, C.POINTER(C.c_int), f64p]
         _lib.ceo_ssimulacra2_score.argtypes = [f64p, C.c_int]
@@ -101,6 +103,14 @@ def sse(ref, test) -> int:
 
 def srgb_u8_to_linear(v: int) -> float:
     return float(lib().ceo_srgb_u8_to_linear(int(v)))
+
+
+def cbrtf_compare(x) -> tuple:
+    """(pinned, host): the oracle's pinned cbrtf (glibc 2.35 restated) and the host libm's on the same inputs."""
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+    pinned, host = np.empty_like(a), np.empty_like(a)
+    lib().ceo_cbrtf_compare(_p(a, C.c_float), a.size, _p(pinned, C.c_float), _p(host, C.c_float))
+    return pinned, host
 
 
 def rgb8_to_dssim_image(rgb, w: int, h: int) -> np.ndarray:

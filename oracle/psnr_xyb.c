@@ -8,8 +8,17 @@
  * none of the cited code does.
  *
  * libm notes: Rust's f32::powf / f32::cbrt / f32::round lower to the platform
- * libm's powf / cbrtf / roundf on linux-gnu, so calling glibc here IS the
- * reference's arithmetic on this host.
+ * libm's powf / cbrtf / roundf on linux-gnu.  powf and roundf are called from
+ * the host libm here (the device builds its sRGB tables from the same host
+ * powf, ce_tables.cpp, so both sides follow the host).  cbrtf is PINNED: its
+ * input is a continuous f32, so no table can stand in for it, and glibc
+ * changed the routine (2.35: frexp / quadratic seed / one f64 Halley step;
+ * later releases ship a correctly rounded one).  Oracle and device both
+ * execute the glibc-2.35 algorithm restated with IEEE basic operations
+ * (ceo_cbrtf_pinned below, cbrtf_glibc_pos in codec-eval_amd/csrc/xyb.hip);
+ * that algorithm reproduces the reference's 2^24-colour known-answer table
+ * (xyb.rs:15-24).  tests/test_oracle_pinning.py reports how the host's own
+ * cbrtf compares.
  */
 #include "ce_oracle.h"
 
@@ -112,8 +121,38 @@ static uint8_t linear_to_srgb_u8(float v)
     if (r > 255.0f) return 255;
     return (uint8_t)r;
 }
+/* glibc 2.35 sysdeps/ieee754/flt-32/s_cbrtf.c for positive normal x, IEEE basic
+ * operations only (the pinned cbrtf, see the header). */
+float ceo_cbrtf_pinned(float x)
+{
+    if (!(x > 0.0f) || !isfinite(x) || x < 1.17549435e-38f) return cbrtf(x); /* never reached from the opsin values */
+    union { float f; uint32_t u; } b, m, o;
+    b.f = x;
+    const int xe = (int)(b.u >> 23) - 126;                 /* frexpf exponent */
+    m.u = (b.u & 0x007fffffu) | 0x3f000000u;               /* mantissa in [0.5, 1) */
+    const float xm = m.f;
+    const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066 * (double)xm) * (double)xm);
+    const float t2 = u * u * u;
+    const int r = xe % 3;
+    const double factor = r == -2 ? 1.0 / 1.5874010519681994748
+                        : r == -1 ? 1.0 / 1.2599210498948731648
+                        : r == 0  ? 1.0
+                        : r == 1  ? 1.2599210498948731648
+                                  : 1.5874010519681994748;
+    const float ym = (float)((double)u * ((double)t2 + 2.0 * (double)xm) / (2.0 * (double)t2 + (double)xm) * factor);
+    o.f = ym;
+    o.u += (uint32_t)(xe / 3) << 23;                       /* ldexpf(ym, xe / 3) */
+    return o.f;
+}
+void ceo_cbrtf_compare(const float *x, size_t n, float *pinned, float *host)
+{
+    for (size_t i = 0; i < n; i++) {
+        pinned[i] = ceo_cbrtf_pinned(x[i]);
+        host[i] = cbrtf(x[i]);
+    }
+}
 /* xyb.rs:92-94 */
-static float mixed_cbrt(float v) { return v < 0.0f ? -cbrtf(-v) : cbrtf(v); }
+static float mixed_cbrt(float v) { return v < 0.0f ? -ceo_cbrtf_pinned(-v) : ceo_cbrtf_pinned(v); }
 /* xyb.rs:98-100 — powi(3) expands to (v*v)*v */
 static float mixed_cube(float v)
 {

@@ -99,6 +99,27 @@ def test_xyb_roundtrip_known_answer_table(oracle):
     assert worst[0] > 200 and worst[1] > 200 and worst[2] < 100  # "bright saturated yellows"
 
 
+def test_xyb_cbrtf_is_pinned_in_one_place(oracle):
+    """xyb.rs:92-94 calls f32::cbrt = the platform libm's cbrtf, whose algorithm changed between glibc releases.
+    Oracle and device both run ONE restatement (glibc 2.35's routine, the one that reproduces the table above).
+    On a glibc-2.35 host the restatement must equal the host's cbrtf bit for bit; on a host with a different
+    cbrtf the test reports the disagreement rate instead of failing (the pin, not the host, is the contract)."""
+    import platform
+
+    rng = np.random.default_rng(5)
+    # the roundtrip's inputs: opsin values in [bias, ~1.004]; plus a wide log-uniform sweep of normal floats
+    x = np.concatenate([rng.uniform(0.0037930733, 1.01, 1 << 20), np.exp(rng.uniform(-80, 80, 1 << 18))]).astype(np.float32)
+    pinned, host = oracle.cbrtf_compare(x)
+    differ = int((pinned.view(np.uint32) != host.view(np.uint32)).sum())
+    ulps = np.abs(pinned.view(np.int32).astype(np.int64) - host.view(np.int32).astype(np.int64)).max()
+    if platform.libc_ver()[1] == "2.35":
+        assert differ == 0
+    elif differ:
+        assert ulps <= 1  # two faithful cube roots never differ by more than one ulp
+        pytest.skip(f"host cbrtf ({platform.libc_ver()}) differs from the pinned glibc-2.35 routine on {differ} of {x.size} "
+                    f"inputs (max {ulps} ulp); oracle and device both use the pin")
+
+
 # ---- SSIMULACRA2: src/metrics/ssimulacra2.rs:153-182 (inequalities only) -----------------------------
 @pytest.mark.parametrize("mode", [0, 1])
 def test_ssimulacra2_reference_tests(oracle, mode):
