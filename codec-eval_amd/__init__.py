@@ -151,6 +151,7 @@ _PROTOTYPES = [
     ("ce_debug_ssim2_averages", _i, [_vp, _u32, _dp, C.POINTER(_i)]),
     ("ce_debug_ssim2_occupancy", _i, [_i]),
     ("ce_debug_cbrt_sweep", _i, [_vp, _u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("ce_debug_calibrate_traffic", _i, [_vp, _sz]),
 ]
 ABI_SYMBOLS = [p[0] for p in _PROTOTYPES]
 
@@ -334,6 +335,10 @@ class Context:
         self._check(lib().ce_ctx_memory_info(self._h, C.byref(free), C.byref(total)))
         return free.value, total.value
 
+    def debug_calibrate_traffic(self, nbytes: int):
+        """Run the known-byte-count calibration streams (profiles/make_traffic.py reads them from a PMC pass)."""
+        self._check(lib().ce_debug_calibrate_traffic(self._h, nbytes))
+
     def debug_cbrt_sweep(self, first_bits: int, count: int):
         """(mismatches, fallbacks) of the fast vs reference cube root over f32 bit patterns."""
         mism, slow = C.c_uint64(), C.c_uint64()
@@ -412,7 +417,7 @@ class Context:
         self._check(lib().ce_prof_enable(self._h, 0 if not on else (1 if serial else 2)))
 
     def prof_filter(self, substring: str = ""):
-        """Only kernels whose name contains `substring` get events ("" = all)."""
+        """Only kernels whose name contains `substring` get events ("" = all, "=name" = exactly that kernel)."""
         self._check(lib().ce_prof_filter(self._h, substring.encode()))
 
     def prof_reset(self):

@@ -973,8 +973,9 @@ int launch_blur_len(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g
 {
     const float inv = inv_weight_sum(bk);
     const dim3 gh((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
-    CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot);
-    CE_LAUNCH(ctx, "ba_blur_v", k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot);
+    static const std::string name_h = "ba_blur_h" + std::to_string(LEN), name_v = "ba_blur_v" + std::to_string(LEN);
+    CE_LAUNCH(ctx, name_h.c_str(), k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot);
+    CE_LAUNCH(ctx, name_v.c_str(), k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot);
     return CE_OK;
 }
 
@@ -1114,15 +1115,15 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
             }
             const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), n_slots * 3), gh2(gh3.x, gh3.y, n_slots * 2);
             const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, n_slots);
-            CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
+            CE_LAUNCH(ctx, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1);
             CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy, g,
                       kLf, inv_weight_sum(kLf), n_refs_used, mr);
-            CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<15>, gh3, dim3(TPB), 0, (const float *)psy, sA, g, sMf, s3, kHf, inv_weight_sum(kHf),
+            CE_LAUNCH(ctx, "ba_blur_h15", k_ba_blur_h<15>, gh3, dim3(TPB), 0, (const float *)psy, sA, g, sMf, s3, kHf, inv_weight_sum(kHf),
                       n_refs_used, mr, 1);
             CE_LAUNCH(ctx, "ba_blur_v_mf", (k_ba_blur_v_split<15, EPI_MF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
                       psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr);
-            CE_LAUNCH(ctx, "ba_blur_h", k_ba_blur_h<7>, gh2, dim3(TPB), 0, (const float *)psy, sA, g, sHf, s2, kUhf, inv_weight_sum(kUhf),
+            CE_LAUNCH(ctx, "ba_blur_h7", k_ba_blur_h<7>, gh2, dim3(TPB), 0, (const float *)psy, sA, g, sHf, s2, kUhf, inv_weight_sum(kUhf),
                       n_refs_used, mr, 1);
             CE_LAUNCH(ctx, "ba_blur_v_hf", (k_ba_blur_v_split<7, EPI_HF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
                       psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr);

@@ -50,7 +50,10 @@ double psnr_from_sse(unsigned long long sse, size_t w, size_t h)
 
 int ce_prof_begin(ce_ctx *ctx, const char *name, hipStream_t stream)
 {
-    if (!ctx->prof_filter.empty() && !std::strstr(name, ctx->prof_filter.c_str())) return -1;
+    if (!ctx->prof_filter.empty()) {  // "=name": that kernel only; otherwise a substring
+        const char *f = ctx->prof_filter.c_str();
+        if (f[0] == '=' ? std::strcmp(name, f + 1) != 0 : !std::strstr(name, f)) return -1;
+    }
     int idx = -1;
     for (size_t i = 0; i < ctx->stats.size(); i++)
         if (ctx->stats[i].name == name) { idx = (int)i; break; }
@@ -532,7 +535,12 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     const bool run_ssim2 = (metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8;
     const bool run_dssim = (metric_mask & CE_METRIC_DSSIM) != 0;
     const bool run_ba = (metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8;
-    const bool fork = !ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1;
+    // CE_METRIC_STREAMS=serial keeps the chains back to back on the context's stream (measurement knob; default: fork)
+    static const bool fork_chains = [] {
+        const char *e = std::getenv("CE_METRIC_STREAMS");
+        return !(e && std::strcmp(e, "serial") == 0);
+    }();
+    const bool fork = fork_chains && !ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1;
     hipStream_t base = ctx->stream;
     if (fork) {
         if (!b->ev_fork) CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -1147,6 +1155,13 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg, int *
 }
 
 int ce_debug_ssim2_occupancy(int which) { return ce_ssim2_occupancy(which); }
+
+int ce_debug_calibrate_traffic(ce_ctx *ctx, size_t bytes)
+{
+    if (!ctx) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    return ce_calibrate_traffic(ctx, bytes);
+}
 
 int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path)
 {

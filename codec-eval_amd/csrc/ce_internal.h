@@ -200,6 +200,7 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
 void ce_dssim_free(ce_batch *b);
 int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs, float intensity_target);
 void ce_butteraugli_free(ce_batch *b);
+int ce_calibrate_traffic(ce_ctx *ctx, size_t bytes);
 int ce_launch_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *d_rgb, float *d_rgba, size_t n_pixels);
 
 // host-side constant builders (ce_tables.cpp)

@@ -27,6 +27,35 @@ def assign_references(pixel_counts: Sequence[int], world_size: int) -> List[List
     return out
 
 
+def imbalance(loads: Sequence[float]) -> float:
+    """max / mean of the per-rank loads (1.0 = perfectly balanced)."""
+    mean = sum(loads) / max(len(loads), 1)
+    return max(loads) / mean if mean > 0 else 1.0
+
+
+def plan_partition(ref_pixels: Sequence[int], tests_per_ref: Sequence[int], variants_per_ref: int, world_size: int,
+                   tolerance: float = 0.01):
+    """partition BY REFERENCE (one upload and one set of reference planes per source image); when
+    there are too few references for the ranks (config 5: 15 images on 8 GPUs) fall back to partitioning by
+    (image, codec-config) unit if that balances strictly better.  Load = pixels x tests.
+
+    Returns (mode, per_rank_units, per_rank_load): mode is "reference" or "image-x-codec-config"; a unit is
+    (reference index, variant index); in "reference" mode a rank owns every variant of its references."""
+    V = max(1, variants_per_ref)
+    ref_load = [p * t for p, t in zip(ref_pixels, tests_per_ref)]
+    by_ref = assign_references(ref_load, world_size)
+    load_ref = [sum(ref_load[i] for i in r) for r in by_ref]
+    units_ref = [[(i, v) for i in r for v in range(V)] for r in by_ref]
+    if V == 1:
+        return "reference", units_ref, load_ref
+    unit_load = [ref_load[i] / V for i in range(len(ref_pixels)) for _ in range(V)]
+    by_unit = assign_references(unit_load, world_size)
+    load_unit = [sum(unit_load[u] for u in r) for r in by_unit]
+    if imbalance(load_unit) < imbalance(load_ref) - tolerance:
+        return "image-x-codec-config", [[(u // V, u % V) for u in r] for r in by_unit], load_unit
+    return "reference", units_ref, load_ref
+
+
 def shard_items(item_refs: Sequence[int], ref_owner: Sequence[int], rank: int) -> List[int]:
     """Indices of the work items (each tagged with its reference index) owned by `rank`."""
     return [k for k, ri in enumerate(item_refs) if ref_owner[ri] == rank]

@@ -102,27 +102,40 @@ def distort(reference: np.ndarray, quality: float, subsampling_420: bool = False
 
 @dataclass
 class Grid:
-    """A (reference x quality) grid of one shape: references[i] is (h, w, 3); pairs[k] = (ref_index, test)."""
+    """A (reference x quality) grid of one shape: references[i] is (h, w, 3); pairs[k] = (ref_index, test).
+    When only a shard of the grid was generated (`only` / `units`), ref_ids[i] is the GLOBAL index of references[i]
+    and pair_ids[k] = (global reference index, variant index, quality index) of pairs[k]."""
     name: str
     width: int
     height: int
     references: List[np.ndarray]
     pairs: List[Tuple[int, np.ndarray]]
+    ref_ids: List[int] = None
+    pair_ids: List[Tuple[int, int, int]] = None
 
     @property
     def megapixels(self) -> float:
         return len(self.pairs) * self.width * self.height / 1e6
 
 
-def _grid(name, w, h, n_refs, seed0, qualities, variants=((False,),), kinds=None) -> Grid:
-    refs, pairs = [], []
-    for i in range(n_refs):
-        kind = (kinds or {}).get(i, "natural")
-        refs.append(make_reference(w, h, seed0 + i, kind))
-        for (s420,) in variants:
-            for q in qualities:
-                pairs.append((i, distort(refs[i], q, s420)))
-    return Grid(name, w, h, refs, pairs)
+def _grid(name, w, h, n_refs, seed0, qualities, variants=((False,),), kinds=None, only=None, units=None) -> Grid:
+    """only: global reference indices to generate (a rank's shard; default all).  units: (reference, variant) pairs
+    to generate instead (partition by (image, codec-config)) - a reference listed with several
+    variants is generated once.  Every image depends on its GLOBAL index only, so any shard of the grid holds the
+    same bytes as the same cells of the whole grid."""
+    if units is None:
+        units = [(i, v) for i in (range(n_refs) if only is None else only) for v in range(len(variants))]
+    refs, pairs, ref_ids, pair_ids, local = [], [], [], [], {}
+    for i, v in units:
+        if i not in local:
+            local[i] = len(refs)
+            refs.append(make_reference(w, h, seed0 + i, (kinds or {}).get(i, "natural")))
+            ref_ids.append(i)
+        (s420,) = variants[v]
+        for qi, q in enumerate(qualities):
+            pairs.append((local[i], distort(refs[local[i]], q, s420)))
+            pair_ids.append((i, v, qi))
+    return Grid(name, w, h, refs, pairs, ref_ids, pair_ids)
 
 
 KODAK_LANDSCAPE, KODAK_PORTRAIT = 18, 6  # SURVEY.md §8d: 768x512 x18 + 512x768 x6
@@ -138,21 +151,42 @@ def kodak_like(qualities=(75, 85, 95), n_landscape=KODAK_LANDSCAPE, n_portrait=K
     return out
 
 
-def uhd_pairs(n=16, seed0=2000, quality=85) -> Grid:
+def kodak_corpus_shapes(copies: int = 1) -> List[Tuple[int, int]]:
+    """(width, height) of every reference of `copies` Kodak-24-shaped sets, global reference order: copy c holds
+    references 24c .. 24c+23, the first 18 of a copy are 768x512, the last 6 are 512x768."""
+    return [((768, 512) if i % 24 < KODAK_LANDSCAPE else (512, 768)) for i in range(24 * copies)]
+
+
+def kodak_corpus_shard(ref_indices, qualities=(75, 85, 95), seed0=1000) -> List[Grid]:
+    """The references `ref_indices` (global indices into kodak_corpus_shapes) with their quality sweep, one Grid per
+    shape.  Reference g is generated from seed0 + g, so shards of different ranks are cells of ONE global grid."""
+    shapes = kodak_corpus_shapes(max(ref_indices) // 24 + 1) if len(ref_indices) else []
+    out = []
+    for (w, h) in ((768, 512), (512, 768)):
+        mine = [g for g in ref_indices if shapes[g] == (w, h)]
+        if mine:
+            out.append(_grid(f"kodak-{w}x{h}", w, h, 0, seed0, qualities, only=mine))
+    return out
+
+
+def uhd_pairs(n=16, seed0=2000, quality=85, only=None) -> Grid:
     """BASELINE configs[2]: synthetic 3840x2160 pairs."""
-    return _grid("uhd-3840x2160", 3840, 2160, n, seed0, (quality,))
+    return _grid("uhd-3840x2160", 3840, 2160, n, seed0, (quality,), only=only)
 
 
 STANDARD_QUALITIES = (50, 60, 70, 75, 80, 85, 90, 95)  # crates/codec-iter/src/main.rs:198
 DENSE_QUALITIES = tuple(range(50, 99, 2))  # main.rs:199
 
 
-def cid22_like(n_refs=250, qualities=STANDARD_QUALITIES, seed0=3000) -> Grid:
+def cid22_like(n_refs=250, qualities=STANDARD_QUALITIES, seed0=3000, only=None) -> Grid:
     """BASELINE configs[3]: CID22-512 shapes x the standard 8-quality sweep."""
-    return _grid("cid22-512x512", 512, 512, n_refs, seed0, qualities)
+    return _grid("cid22-512x512", 512, 512, n_refs, seed0, qualities, only=only)
 
 
-def codec_iter_dense(n_refs=15, qualities=DENSE_QUALITIES, seed0=4000) -> Grid:
+DENSE_VARIANTS = ((False,), (True,))  # 4:4:4, 4:2:0 (crates/codec-iter/src/main.rs:474-499)
+
+
+def codec_iter_dense(n_refs=15, qualities=DENSE_QUALITIES, seed0=4000, only=None, units=None) -> Grid:
     """BASELINE configs[4]: 15-image tier x 25 qualities x {4:4:4, 4:2:0} (the XYB on/off axis is a
-    metric flag, applied by the caller)."""
-    return _grid("codec-iter-512x512", 512, 512, n_refs, seed0, qualities, variants=((False,), (True,)))
+    metric flag, applied by the caller).  units: (reference, variant) cells of a rank's shard."""
+    return _grid("codec-iter-512x512", 512, 512, n_refs, seed0, qualities, variants=DENSE_VARIANTS, only=only, units=units)

@@ -207,7 +207,7 @@ void ce_ref_destroy(ce_ref *ref);
  * kernel trace sees).  on = 1: additionally keep all launches on the context's stream, one kernel at a
  * time ("solo" times). */
 int ce_prof_enable(ce_ctx *ctx, int on);
-/* restrict the events to kernels whose name contains `substring` (NULL or "" = all kernels) */
+/* restrict the events to kernels whose name contains `substring` (NULL or "" = all kernels; "=name" = exactly that kernel) */
 int ce_prof_filter(ce_ctx *ctx, const char *substring);
 int ce_prof_reset(ce_ctx *ctx);
 /* number of distinct kernels seen; then per index: name, launches, total ms */
@@ -234,6 +234,10 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg /* [6]
 /* resident workgroups per CU that the HIP runtime reports for the SSIMULACRA2 row pass (0) / column pass (1) */
 int ce_debug_ssim2_occupancy(int which);
 int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path);
+/* Known-byte-count streams for calibrating the rocprofv3 traffic counters: reads `bytes` of a scratch buffer with 1, 4
+ * and 16 bytes per lane and writes it with 4 and 16 (kernels k_calib_read<W> / k_calib_write<W>), so a PMC pass can
+ * measure FETCH_SIZE's / WRITE_SIZE's correction factor per access width (profiles/make_traffic.py). */
+int ce_debug_calibrate_traffic(ce_ctx *ctx, size_t bytes);
 
 #ifdef __cplusplus
 }

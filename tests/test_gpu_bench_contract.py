@@ -29,12 +29,26 @@ def test_single_gpu_line():
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["unit"] == "MP/s" and d["scaling"] == "weak"
     assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the line measures the metric it names: all three perceptual metrics on every pair, with a per-metric breakdown
+    assert set(d["config"]["metrics"]) == {"ssimulacra2", "dssim", "butteraugli"} and d["config"]["metric_evaluations_per_pair"] == 3
+    assert set(d["per_metric"]) == {"ssimulacra2", "dssim", "butteraugli"} and all(v["value"] > 0 for v in d["per_metric"].values())
     r = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] == "hbm" and r["peak"] == 8000.0
+    assert {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms"} <= set(r)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["kernel"] in r["kernels"]
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+    # frac is recomputable from the line alone: algorithmic bytes per launch / average launch duration / peak
+    assert abs(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"] - r["frac"]) < 2e-3
+    assert 0.0 < r["in_region_frac"] <= 1.0 and 0.0 < r["pipeline_frac"] < 1.0
+    # the dominant kernel is the one with the largest solo time, and every data-moving kernel has its own row
+    rows = {k: v for k, v in r["kernels"].items() if "solo_frac" in v}
+    assert r["kernel"] == max(rows, key=lambda k: rows[k]["solo_ms_per_step"])
+    assert {"ssim2_vblur_ssim_L0", "dssim_compare", "ba_malta_l2", "ba_blur_h33"} <= set(rows)
     c = d["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0
-    assert d["value"] > c["value"] and d["max_rel_dev_vs_oracle"] < 1e-4
+    assert c["cores"] <= c["host_cores"] and set(c["value_1thread_per_metric"]) == {"ssimulacra2", "dssim", "butteraugli"}
+    assert d["value"] > c["value"] and all(v < 1e-4 for v in d["max_rel_dev_vs_oracle"].values())
+    e = d["end_to_end"]
+    assert e["unit"] == "MP/s" and 0 < e["value"] <= d["value"] * 1.05
 
 
 def test_two_rank_path_sharing_one_device():
@@ -47,5 +61,24 @@ def test_two_rank_path_sharing_one_device():
     assert len(lines) == 1  # rank 0 only
     d = lines[0]
     assert d["n_gpus"] == 2 and d["cpu_baseline"] is None  # the CPU baseline is an N = 1 measurement
-    # whole-job value = both ranks' pixels over the slower rank's time
-    assert abs(d["value"] - 2 * d["config"]["megapixels_per_gpu_step"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-2 * d["value"]
+    # whole-job value = both ranks' (pair, metric) evaluations over the slower rank's time
+    assert abs(d["value"] - 3 * d["config"]["megapixels_per_step"] * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-2 * d["value"]
+    # ONE global grid was partitioned: the shards tile it, the gathered scores are complete and a foreign shard's item
+    # recomputed on rank 0 is bit-identical
+    sh = d["shard"]
+    assert sh["partition"] == "reference" and len(sh["pairs_per_rank"]) == 2 and sum(sh["pairs_per_rank"]) == d["config"]["pairs_per_step"] == 36
+    assert sh["gathered_scores"] == 36 and sh["recomputed_on_rank0"] >= 1 and sh["recomputed_max_abs_diff"] == 0.0
+    assert sh["imbalance_max_over_mean"] == 1.0
+
+
+def test_two_rank_fixed_grid_strong_scaling_with_unit_fallback():
+    """configs[4] (few references): the fixed grid is split by (image, codec-config) when that balances better."""
+    env = dict(os.environ, CE_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", "bench.py", "--gpus", "2", "--config", "5", "--refs", "3", "--steps", "2", "--warmup", "1", "--no-solo"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _json_lines(out.stdout)[0]
+    assert d["scaling"] == "strong" and d["config"]["pairs_per_step"] == 300
+    sh = d["shard"]
+    assert sh["partition"] == "image-x-codec-config" and sh["pairs_per_rank"] == [150, 150] and sh["recomputed_max_abs_diff"] == 0.0

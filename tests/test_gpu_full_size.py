@@ -3,8 +3,8 @@
 configs[2] works on 3840x2160 images: one such pair is scored by every metric and compared with the oracle directly
 (the C oracle needs ~40 s of one host core for it), and the whole config-3 batch is checked through properties that do
 not depend on size (identity, batch == single, permutation of pairs, monotonic in the distortion strength).
-configs[1]/[3]/[4] sizes (768x512, 512x768, 512x512) are compared with the oracle directly in test_gpu_parity.py /
-test_gpu_butteraugli.py."""
+configs[1] sizes (768x512, 512x768) are compared with the oracle directly in test_gpu_parity.py / test_gpu_butteraugli.py,
+configs[3] / configs[4] (512x512 grids) in test_gpu_configs.py."""
 import numpy as np
 import pytest
 
@@ -27,6 +27,14 @@ def test_4k_pair_every_metric_against_the_oracle(gpu_ctx, oracle, ce, workloads)
     assert rel(m.dssim, oracle.dssim(ref, test, W, H), 1e-6) <= 1e-4
     want, want_p3 = oracle.butteraugli(ref, test, W, H)
     assert rel(m.butteraugli, want, 1e-3) <= 1e-4
+    # BASELINE configs[2] names the 3-norm (libjxl's mean of the 3-, 6- and 12-norms of the diffmap)
+    b = ce.Batch(gpu_ctx, W, H, 1, 1)
+    b.set_reference(0, ref)
+    b.set_test(0, 0, test)
+    s = b.run(1, ce.MetricConfig(butteraugli=True))
+    assert s[0].butteraugli == m.butteraugli
+    assert rel(float(b.butteraugli_pnorm3(1)[0]), want_p3, 1e-3) <= 1e-4
+    b.close()
     rt = gpu_ctx.xyb_roundtrip(ref, W, H)
     assert np.array_equal(rt, oracle.xyb_roundtrip(ref, W, H))  # u8-exact on all 8.3 M pixels
 

@@ -25,6 +25,38 @@ def test_assignment_is_balanced_and_complete():
     assert sh.assign_references([5], 4) == [[0], [], [], []]
 
 
+def test_partition_plan_falls_back_to_image_x_codec_config():
+    # configs[3]: 250 references on 8 ranks: by reference, 2.4 % off balance at most
+    mode, units, loads = sh.plan_partition([512 * 512] * 250, [8] * 250, 1, 8)
+    assert mode == "reference" and sorted(len(u) for u in units) == [31] * 6 + [32] * 2 and sh.imbalance(loads) < 1.03
+    # configs[4]: 15 references x 4 codec configs.  2 and 4 ranks balance exactly by (image, codec-config) units;
+    # on 8 ranks both partitions are 8 / 7.5 off, so the references stay whole (one upload, shared reference planes)
+    for world, want_mode, per_rank in ((1, "reference", [60]), (2, "image-x-codec-config", [30, 30]),
+                                       (4, "image-x-codec-config", [15] * 4), (8, "reference", [8] * 7 + [4])):
+        mode, units, loads = sh.plan_partition([512 * 512] * 15, [100] * 15, 4, world)
+        assert mode == want_mode and [len(u) for u in units] == per_rank, (world, mode, [len(u) for u in units])
+        flat = sorted(x for u in units for x in u)
+        assert flat == [(i, v) for i in range(15) for v in range(4)]  # every unit exactly once
+    # mixed pixel counts: LPT by load
+    mode, units, loads = sh.plan_partition([100, 100, 400], [2, 2, 2], 1, 2)
+    assert sorted(loads) == [400, 800] and mode == "reference"
+
+
+def test_shards_are_cells_of_one_global_grid():
+    """A rank generates only its own references, from their GLOBAL indices: the bytes equal the same cells of the whole grid."""
+    wl = importlib.import_module("codec-eval_amd.workloads")
+    whole = wl.kodak_like((75,), 2, 1)  # references 0, 1 (768x512) and 18 (512x768) of a Kodak-24 set
+    part = wl.kodak_corpus_shard([1, 18], (75,))
+    assert [g.ref_ids for g in part] == [[1], [18]] and [g.pair_ids for g in part] == [[(1, 0, 0)], [(18, 0, 0)]]
+    assert np.array_equal(part[0].references[0], whole[0].references[1]) and np.array_equal(part[0].pairs[0][1], whole[0].pairs[1][1])
+    assert np.array_equal(part[1].references[0], whole[1].references[0]) and np.array_equal(part[1].pairs[0][1], whole[1].pairs[0][1])
+    assert wl.kodak_corpus_shapes(2)[17:19] + wl.kodak_corpus_shapes(2)[41:43] == [(768, 512), (512, 768)] * 2
+    dense = wl.codec_iter_dense(2, qualities=(50, 98))
+    unit = wl.codec_iter_dense(2, qualities=(50, 98), units=[(1, 1)])  # reference 1, 4:2:0 only
+    assert unit.ref_ids == [1] and unit.pair_ids == [(1, 1, 0), (1, 1, 1)]
+    assert np.array_equal(unit.pairs[0][1], dense.pairs[6][1]) and np.array_equal(unit.pairs[1][1], dense.pairs[7][1])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
