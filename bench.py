@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="timed region with every launch on one stream, one kernel at a time (for rocprofv3 traces whose per-kernel "
                          "durations are the kernels' own, not their share of an overlapped schedule)")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight per shape bucket (default: 2 for one-metric configs, else 1)")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight per shape bucket (default 2: step k+1 is launched before step k's scores are collected)")
     return ap.parse_args()
 
 
@@ -180,7 +180,7 @@ def main():
     # One context (= one HIP stream family) per batch, so the buckets' kernel chains overlap on the GPU.  depth > 1 keeps
     # that many sets of batches in flight (step k is launched before step k-1's scores are collected, the way a session
     # streams a corpus larger than one batch); every timed step's scores are still collected inside the timed region.
-    depth = args.depth if args.depth > 0 else (2 if len(metrics_on) == 1 else 1)
+    depth = args.depth if args.depth > 0 else 2
     sets = []
     for _ in range(depth):
         bs = []
@@ -563,7 +563,9 @@ def main():
                 "sharding": f"global grid of {n_global_refs} references partitioned by {partition_mode}, one process per GPU, no collective on the data path",
                 "inputs": "resident in HBM (uploaded before the timed region)",
                 "batches_in_flight": depth,
-                "schedule": "serial (one stream)" if args.serial else "metric chains, shape buckets and in-flight steps overlap on their own HIP streams",
+                "schedule": "serial (one stream, one kernel at a time)" if args.serial else
+                            ("shape buckets and in-flight steps overlap on their own HIP streams; a batch's metric chains run "
+                             + ("side by side (CE_METRIC_STREAMS=fork)" if os.environ.get("CE_METRIC_STREAMS") == "fork" else "back to back")),
                 "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             },
             "roofline": roofline,

@@ -106,6 +106,7 @@ extern "C" {
                           out: *mut ce_scores) -> c_int;
     pub fn ce_ref_compare_many(r: *mut ce_ref, tests: *const *const u8, test_lens: *const usize, n_tests: u32, metric_mask: u32,
                                intensity_target: c_float, out: *mut ce_scores) -> c_int;
+    pub fn ce_ref_stats(r: *const ce_ref, builds: *mut u32) -> c_int;
     pub fn ce_ref_destroy(r: *mut ce_ref);
     pub fn ce_prof_enable(ctx: *mut ce_ctx, on: c_int) -> c_int;
     pub fn ce_prof_filter(ctx: *mut ce_ctx, substring: *const c_char) -> c_int;

@@ -138,6 +138,7 @@ _PROTOTYPES = [
     ("ce_ref_create", _i, [_vp, _u8p, _sz, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("ce_ref_compare", _i, [_vp, _u8p, _sz, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_ref_compare_many", _i, [_vp, C.POINTER(_u8p), C.POINTER(_sz), _u32, _u32, _f32, C.POINTER(CeScores)]),
+    ("ce_ref_stats", _i, [_vp, C.POINTER(_u32 * 3)]),
     ("ce_ref_destroy", None, [_vp]),
     ("ce_prof_enable", _i, [_vp, _i]),
     ("ce_prof_filter", _i, [_vp, C.c_char_p]),
@@ -558,6 +559,12 @@ class ReferenceHandle:
         for s in out:
             res.append(MetricResult.from_c(s) if s.status == 0 else _error_obj(s.status, self.ctx._err()))
         return res
+
+    def stats(self):
+        """(ssimulacra2, dssim, butteraugli): compares so far that had to build that metric's reference-side state."""
+        out = (_u32 * 3)()
+        self.ctx._check(lib().ce_ref_stats(self._h, C.byref(out)))
+        return tuple(out)
 
     def close(self):
         if self._h and self.ctx._h:

@@ -55,12 +55,12 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, ui
 // ---- SubSample2x straight from the u8 slabs: out(x/2, y/2) += 0.25 * lin(x, y) in raster order; odd edges doubled ----
 __global__ __launch_bounds__(TPB) void k_ba_subsample2x_u8(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
                                                            const float *__restrict__ lut, float *__restrict__ out, geom gi, geom g,
-                                                           size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+                                                           size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
 {
     __shared__ float s_lut[256];
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
-    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);  // z0 > 0: the references' PsychoImage is cached
     const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
     BA_XY;
     float acc[3] = {0.0f, 0.0f, 0.0f};
@@ -134,12 +134,12 @@ constexpr int BH_TILES = 4;  // 8-row tiles per block of the row blur
 template <int LEN>
 __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
                                                    plane_sel so, blur_kernel bk, float inv_wsum, uint32_t n_refs_used,
-                                                   uint32_t max_refs, int by_slot)
+                                                   uint32_t max_refs, int by_slot, uint32_t z0)
 {
     constexpr int off = LEN / 2, TW = 256, TR = 8, LEFT = 16, RAW = TW + 2 * LEFT, ROWF = RAW + RAW / 8 + 1, SH = LEFT - off;
     static_assert(off <= LEFT, "tile halo");
     __shared__ float tile[TR * ROWF];
-    const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
+    const uint32_t u = blockIdx.z / si.n + z0, k = blockIdx.z % si.n;
     const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
     const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
     const int x0 = blockIdx.x * TW;
@@ -295,13 +295,14 @@ template <bool FROM_U8>
 __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
                                                   const float *__restrict__ lut, const float *__restrict__ lin_in,
                                                   float *__restrict__ xyb, geom g, float w0, float w1, float w2,
-                                                  float intensity_target, size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+                                                  float intensity_target, size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs,
+                                                  uint32_t z0)
 {
     __shared__ float L[3][FR * FR];   // linear, region = tile + 2
     __shared__ float H[3][FR * FT];   // row-blurred: FR rows x FT columns
     __shared__ float s_lut[256];
     if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
-    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);
     const int w = (int)g.w, h = (int)g.h, x0 = blockIdx.x * FT, y0 = blockIdx.y * FT, gx0 = x0 - 2, gy0 = y0 - 2;
     const uint8_t *src8 = nullptr;
     if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
@@ -428,13 +429,13 @@ enum { EPI_LF = 0, EPI_MF = 1, EPI_HF = 2 };
 template <int LEN, int EPI>
 __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict__ tmp, const float *__restrict__ xyb,
                                                          float *__restrict__ psy, geom g, blur_kernel bk, float inv_wsum,
-                                                         uint32_t n_refs_used, uint32_t max_refs)
+                                                         uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
 {
     constexpr int NP = EPI == EPI_HF ? 2 : 3;
     // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
     constexpr int off = LEN / 2, TW = 64, TR = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
     __shared__ __attribute__((aligned(16))) float tile[RAW * TW];
-    const uint32_t slot = slot_of(blockIdx.z, n_refs_used, max_refs);
+    const uint32_t slot = slot_of(blockIdx.z + z0, n_refs_used, max_refs);
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
     const int c = threadIdx.x & 63, wv = threadIdx.x >> 6, gx = x0 + c;
     const bool col_live = gx < (int)g.w;
@@ -974,7 +975,7 @@ int launch_blur_len(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g
     const float inv = inv_weight_sum(bk);
     const dim3 gh((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
     static const std::string name_h = "ba_blur_h" + std::to_string(LEN), name_v = "ba_blur_v" + std::to_string(LEN);
-    CE_LAUNCH(ctx, name_h.c_str(), k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot);
+    CE_LAUNCH(ctx, name_h.c_str(), k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot, 0u);
     CE_LAUNCH(ctx, name_v.c_str(), k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot);
     return CE_OK;
 }
@@ -1020,6 +1021,7 @@ void ce_butteraugli_free(ce_batch *b)
     b->ba_blk_max = nullptr;
     b->ba_blk_sums = nullptr;
     b->ba_pnorm = nullptr;
+    b->ba_ref_src = nullptr;
     b->ba_ready = false;
 }
 
@@ -1073,6 +1075,11 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     int rc = ba_prepare(b);
     if (rc != CE_OK) return rc;
     const uint32_t n_slots = n_refs_used + n_pairs, mr = b->max_refs, P = b->max_pairs;
+    // reference handle (ce_ref_*): the references' PsychoImage (both resolutions) of an earlier launch with the same
+    // intensity target is still in ba_psy, so only the distorted slots go through the per-image chain
+    const bool cached = b->keep_ref_pyramid && b->ba_ref_src == d_refs && b->ba_ref_count >= n_refs_used && b->ba_ref_intensity == intensity_target;
+    const uint32_t z0 = cached ? n_refs_used : 0, nz = n_slots - z0;
+    if (!cached) b->ref_builds[2]++;
     const blur_kernel k12 = make_kernel(1.2f), kLf = make_kernel(7.15593339443f), kHf = make_kernel(3.22489901262f),
                       kUhf = make_kernel(1.56416327805f), kMask = make_kernel(2.7f);
     float sw = 0.0f;
@@ -1094,16 +1101,16 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         float *lin = b->ba_lin[l], *psy = b->ba_psy[l], *sA = b->ba_s[0], *sC = b->ba_s[2];
         // ---- per image slot: PsychoImage ----
         const plane_sel s3{3, 0, 3};
-        const dim3 ft((d.w + FT - 1) / FT, (d.h + FT - 1) / FT, n_slots);
+        const dim3 ft((d.w + FT - 1) / FT, (d.h + FT - 1) / FT, nz);
         if (l == 0) {
             CE_LAUNCH(ctx, "ba_front_u8", k_ba_front<true>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
-                      (const float *)nullptr, sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr);
+                      (const float *)nullptr, sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
         } else {
             const auto &pd = b->ba[0];
-            CE_LAUNCH(ctx, "ba_subsample2x", k_ba_subsample2x_u8, G(n_slots), dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, lin,
-                      geom{pd.w, pd.h, pd.pitch, pd.plane}, g, b->img_bytes, n_refs_used, mr);
+            CE_LAUNCH(ctx, "ba_subsample2x", k_ba_subsample2x_u8, G(nz), dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, lin,
+                      geom{pd.w, pd.h, pd.pitch, pd.plane}, g, b->img_bytes, n_refs_used, mr, z0);
             CE_LAUNCH(ctx, "ba_front", k_ba_front<false>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, (const float *)lin,
-                      sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr);
+                      sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
         }
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
         const plane_sel sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
@@ -1113,20 +1120,20 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                 ctx->err = "unexpected blur kernel length";
                 return CE_ERR_BACKEND;
             }
-            const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), n_slots * 3), gh2(gh3.x, gh3.y, n_slots * 2);
-            const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, n_slots);
+            const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), nz * 3), gh2(gh3.x, gh3.y, nz * 2);
+            const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, nz);
             CE_LAUNCH(ctx, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
-                      n_refs_used, mr, 1);
+                      n_refs_used, mr, 1, z0);
             CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy, g,
-                      kLf, inv_weight_sum(kLf), n_refs_used, mr);
+                      kLf, inv_weight_sum(kLf), n_refs_used, mr, z0);
             CE_LAUNCH(ctx, "ba_blur_h15", k_ba_blur_h<15>, gh3, dim3(TPB), 0, (const float *)psy, sA, g, sMf, s3, kHf, inv_weight_sum(kHf),
-                      n_refs_used, mr, 1);
+                      n_refs_used, mr, 1, z0);
             CE_LAUNCH(ctx, "ba_blur_v_mf", (k_ba_blur_v_split<15, EPI_MF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
-                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr);
+                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0);
             CE_LAUNCH(ctx, "ba_blur_h7", k_ba_blur_h<7>, gh2, dim3(TPB), 0, (const float *)psy, sA, g, sHf, s2, kUhf, inv_weight_sum(kUhf),
-                      n_refs_used, mr, 1);
+                      n_refs_used, mr, 1, z0);
             CE_LAUNCH(ctx, "ba_blur_v_hf", (k_ba_blur_v_split<7, EPI_HF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
-                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr);
+                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0);
         }
 
         // ---- per pair ----
@@ -1143,6 +1150,11 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         if ((rc = launch_blur(ctx, m0, tmp, bl0, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
         if ((rc = launch_blur(ctx, m1, tmp, bl1, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
         CE_LAUNCH(ctx, "ba_mask_combine", k_ba_mask_combine, G(n_pairs), dim3(TPB), 0, bl0, bl1, ac, dc, b->ba_diff[l], g, P);
+    }
+    if (b->keep_ref_pyramid && !cached) {
+        b->ba_ref_src = d_refs;
+        b->ba_ref_count = n_refs_used;
+        b->ba_ref_intensity = intensity_target;
     }
     const auto &d0 = b->ba[0];
     const geom g0{d0.w, d0.h, d0.pitch, d0.plane};

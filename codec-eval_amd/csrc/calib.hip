@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void k_calib_read(const typename lane_word<WID
 {
     uint32_t acc = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= fold(buf[i]);
-    if (acc == 0x9e3779b9u) sink[0] = acc;  // keeps the loads alive; practically never taken
+    if (acc == sink[1]) sink[0] = acc;  // a run-time value the compiler cannot rule out (a constant out of a byte's range
+                                        // let it delete the 1-byte loads): keeps every load alive
 }
 
 template <int WIDTH>
@@ -48,6 +49,7 @@ int ce_calibrate_traffic(ce_ctx *ctx, size_t bytes)
     CE_HIP(ctx, hipMalloc(&buf, bytes));
     CE_HIP(ctx, hipMalloc(&sink, 256));
     CE_HIP(ctx, hipMemsetAsync(buf, 1, bytes, ctx->stream));
+    CE_HIP(ctx, hipMemsetAsync(sink, 0x5a, 256, ctx->stream));
     const dim3 grid(8192), block(256);
     CE_LAUNCH(ctx, "calib_read_b1", k_calib_read<1>, grid, block, 0, (const uint8_t *)buf, bytes, sink);
     CE_LAUNCH(ctx, "calib_read_b4", k_calib_read<4>, grid, block, 0, (const uint32_t *)buf, bytes / 4, sink);

@@ -268,6 +268,16 @@ void ce_batch_destroy(ce_batch *b)
     delete b;
 }
 
+// the reference slab is about to change: whatever was derived from it (XYB roundtrip, SSIMULACRA2 XYB pyramid, DSSIM
+// img / mu / sq pyramid, Butteraugli PsychoImage) is rebuilt by the next launch
+static void invalidate_reference_state(ce_batch *b)
+{
+    b->ssim2_ref_src = nullptr;
+    b->ds_ref_src = nullptr;
+    b->ba_ref_src = nullptr;
+    b->refs_rt_valid = false;
+}
+
 static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src)
 {
     ce_ctx *ctx = b->ctx;
@@ -401,8 +411,7 @@ int ce_batch_set_reference(ce_batch *b, uint32_t ref_index, const uint8_t *rgb, 
     if (len != b->img_bytes)
         return fail(b->ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(b->img_bytes) +
                                                     " bytes, got " + std::to_string(len));
-    b->ssim2_ref_src = nullptr;  // cached reference-side planes are stale
-    b->refs_rt_valid = false;
+    invalidate_reference_state(b);  // cached reference-side planes are stale
     return upload(b, b->d_refs + (size_t)ref_index * b->img_bytes, rgb);
 }
 
@@ -438,8 +447,7 @@ int ce_batch_set_reference_fmt(ce_batch *b, uint32_t ref_index, const void *pixe
 {
     if (!b || !pixels) return CE_ERR_INVALID_ARG;
     if (ref_index >= b->max_refs) return fail(b->ctx, CE_ERR_INVALID_ARG, "ref_index out of range");
-    b->ssim2_ref_src = nullptr;
-    b->refs_rt_valid = false;
+    invalidate_reference_state(b);
     return upload_fmt(b, b->d_refs + (size_t)ref_index * b->img_bytes, pixels, len, format);
 }
 
@@ -478,8 +486,7 @@ int ce_batch_set_test_fmt(ce_batch *b, uint32_t pair_index, uint32_t ref_index, 
 void *ce_batch_reference_slab(ce_batch *b)
 {
     if (!b) return nullptr;
-    b->ssim2_ref_src = nullptr;  // the caller may overwrite references behind our back
-    b->refs_rt_valid = false;
+    invalidate_reference_state(b);  // the caller may overwrite references behind our back
     return b->d_refs;
 }
 void *ce_batch_test_slab(ce_batch *b) { return b ? b->d_tests : nullptr; }
@@ -528,17 +535,18 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         int rc = ce_launch_psnr(b, d_refs, n_pairs);
         if (rc != CE_OK) return rc;
     }
-    // The three perceptual metrics are independent chains over their own buffers.  When a launch runs more than one,
-    // each chain goes to its own stream (forked from / joined back to the context's stream): DSSIM's image builder and
-    // Butteraugli's Malta kernel are VALU-bound, the SSIMULACRA2 passes HBM-bound, and side by side they fill each
-    // other's idle resource.  The serial profiling mode keeps everything on one stream.
+    // The three perceptual metrics are independent chains over their own buffers.
     const bool run_ssim2 = (metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8;
     const bool run_dssim = (metric_mask & CE_METRIC_DSSIM) != 0;
     const bool run_ba = (metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8;
-    // CE_METRIC_STREAMS=serial keeps the chains back to back on the context's stream (measurement knob; default: fork)
+    // Measured (profiles/README.md, round 2): on the Kodak grid the forked chains take 8.7 ms per step, the same chains
+    // back to back 7.3 ms (6.8 with two steps in flight) - side by side they evict each other's reference planes from
+    // L2 and halve each other's resident workgroups.  So the default keeps the chains back to back on the context's
+    // stream (SSIMULACRA2 still overlaps its level-0 passes with its tail levels); CE_METRIC_STREAMS=fork restores the
+    // forked schedule for A/B runs.
     static const bool fork_chains = [] {
         const char *e = std::getenv("CE_METRIC_STREAMS");
-        return !(e && std::strcmp(e, "serial") == 0);
+        return e && std::strcmp(e, "fork") == 0;
     }();
     const bool fork = fork_chains && !ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1;
     hipStream_t base = ctx->stream;
@@ -816,8 +824,7 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
                     k++;
                 }
             }
-            b->ssim2_ref_src = nullptr;
-            b->refs_rt_valid = false;
+            invalidate_reference_state(b);
             rc = upload_many(b, jobs);
             if (rc != CE_OK) return rc;
             rc = ce_batch_launch(b, k, metric_mask, flags, intensity_target);
@@ -985,6 +992,7 @@ int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *
         CE_HIP(ctx, hipMemcpyAsync(nb->d_refs, b->d_refs, b->img_bytes, hipMemcpyDeviceToDevice, ctx->stream));
         CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
         nb->keep_ref_pyramid = true;
+        for (int k = 0; k < 3; k++) nb->ref_builds[k] = b->ref_builds[k];  // the handle's history (ce_ref_stats) carries over
         ce_batch_destroy(b);
         ref->batch = b = nb;
     }
@@ -1025,6 +1033,13 @@ int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t m
     int rc = ce_ref_compare_many(ref, &test, &test_len, 1, metric_mask, intensity_target, out);
     if (rc != CE_OK) return rc;
     return out->status;
+}
+
+int ce_ref_stats(const ce_ref *ref, uint32_t builds[3])
+{
+    if (!ref || !builds) return CE_ERR_INVALID_ARG;
+    for (int k = 0; k < 3; k++) builds[k] = ref->batch->ref_builds[k];
+    return CE_OK;
 }
 
 void ce_ref_destroy(ce_ref *ref)

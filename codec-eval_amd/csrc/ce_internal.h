@@ -128,6 +128,8 @@ struct ce_batch {
     int ssim2_ref_levels = 0;
     bool refs_rt_valid = false;              // d_refs_rt holds the XYB roundtrip of the current references
     int debug_max_scales = CE_MAX_SCALES;  // test hook: stop the pyramid early
+    // launches in which the reference-side state of [SSIMULACRA2, DSSIM, Butteraugli] was (re)built (ce_ref_stats)
+    uint32_t ref_builds[3] = {0, 0, 0};
 
     // DSSIM working set (dssim.hip); planes are [slot][3][plane] with the level's own geometry
     struct dssim_level { uint32_t w, h, pitch; size_t plane; };
@@ -137,6 +139,9 @@ struct ce_batch {
     float *ds_img = nullptr;   // L, a', b' (chroma pre-blurred)
     float *ds_mu = nullptr;    // blur(img)
     float *ds_sq = nullptr;    // blur(img*img)
+    float *ds_rimg[CE_DSSIM_SCALES] = {}, *ds_rmu[CE_DSSIM_SCALES] = {}, *ds_rsq[CE_DSSIM_SCALES] = {};  // the references' planes, per level: [max_refs][3][plane_l]
+    const uint8_t *ds_ref_src = nullptr;  // reference slab those planes were built from (valid while keep_ref_pyramid)
+    uint32_t ds_ref_count = 0;
     float *ds_tmp[2] = {};     // blur pass scratch
     float *ds_i12 = nullptr;   // [pairs][3][plane] blur(img1*img2)
     float *ds_map = nullptr;   // [pairs][plane] SSIM map
@@ -159,6 +164,9 @@ struct ce_batch {
     double *ba_pnorm = nullptr;  // [pair] libjxl 3-norm of the last run
     uint32_t ba_blocks = 0;
     bool ba_ready = false;
+    const uint8_t *ba_ref_src = nullptr;  // reference slab the references' PsychoImage in ba_psy was built from
+    uint32_t ba_ref_count = 0;
+    float ba_ref_intensity = 0.0f;
 
     uint32_t last_n_pairs = 0;
     uint32_t last_mask = 0;

@@ -176,13 +176,19 @@ template <bool FROM_U8>
 __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
                                                       const float *__restrict__ lut, const float *__restrict__ lin_in,
                                                       float *__restrict__ lin_out, float *__restrict__ img, float *__restrict__ mu,
-                                                      float *__restrict__ sq, lvl_geom g, lvl_geom gn, int has_next,
-                                                      size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs)
+                                                      float *__restrict__ sq, float *__restrict__ rimg, float *__restrict__ rmu,
+                                                      float *__restrict__ rsq, lvl_geom g, lvl_geom gn, int has_next,
+                                                      size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
 {
     __shared__ float P[6][DR * DR];
     __shared__ float s_lut[256];
     if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
-    const uint32_t z = blockIdx.z, slot = slot_of(z, n_refs_used, max_refs);
+    // z0 > 0: the references' planes of this level are cached (reference handle), only the distorted slots are built
+    const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);
+    // a reference's img / mu / sq go to its own per-level buffers (slot z there) so that they survive the level loop
+    // and the next launches; a distorted image's go to the shared per-launch buffers (slot max_refs + pair)
+    const bool is_ref = z < n_refs_used;
+    float *oimg = is_ref ? rimg : img, *omu = is_ref ? rmu : mu, *osq = is_ref ? rsq : sq;
     const int w = (int)g.w, h = (int)g.h;
     const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 4, gy0 = y0 - 4;
     const uint8_t *src8 = nullptr;
@@ -226,9 +232,9 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
     // S1..S4 (two chroma pre-blur passes, two passes each for mu and sq, stores): a block whose 40x40 region is
     // wholly inside the image takes the variant without clamping or bounds tests
     if (gx0 >= 0 && gy0 >= 0 && gx0 + DR <= w && gy0 + DR <= h)
-        dssim_create_stages<true>(P, img, mu, sq, g, slot, x0, y0);
+        dssim_create_stages<true>(P, oimg, omu, osq, g, slot, x0, y0);
     else
-        dssim_create_stages<false>(P, img, mu, sq, g, slot, x0, y0);
+        dssim_create_stages<false>(P, oimg, omu, osq, g, slot, x0, y0);
 }
 
 __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -250,7 +256,8 @@ constexpr int CR = DT + 4;
 // the blur of img1*img2 (second pass) and compare_scale on the LDS planes; IN = the block's 36x36 region is inside the image
 template <bool IN>
 __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], float (&T)[3][CR * CR], const float *__restrict__ mu,
-                                                       const float *__restrict__ sq, float *__restrict__ map, const lvl_geom &g,
+                                                       const float *__restrict__ sq, const float *__restrict__ rmu,
+                                                       const float *__restrict__ rsq, float *__restrict__ map, const lvl_geom &g,
                                                        size_t sa, size_t sb, uint32_t p, int x0, int y0)
 {
     const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 2, gy0 = y0 - 2;
@@ -271,11 +278,11 @@ __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], f
             float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float u1 = mu[sa + c * g.plane + o], u2 = mu[sb + c * g.plane + o];
+                const float u1 = rmu[sa + c * g.plane + o], u2 = mu[sb + c * g.plane + o];
                 m11[c] = u1 * u1;
                 m12[c] = u1 * u2;
                 m22[c] = u2 * u2;
-                s1[c] = sq[sa + c * g.plane + o] - m11[c];
+                s1[c] = rsq[sa + c * g.plane + o] - m11[c];
                 s2[c] = sq[sb + c * g.plane + o] - m22[c];
                 s12[c] = pass3x3<CR, false, IN>(T[c], lx, ly, gx0, gy0, w, h) - m12[c];
             }
@@ -292,7 +299,9 @@ __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], f
 }
 
 __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ mu,
-                                                       const float *__restrict__ sq, const uint32_t *__restrict__ pair_ref,
+                                                       const float *__restrict__ sq, const float *__restrict__ rimg,
+                                                       const float *__restrict__ rmu, const float *__restrict__ rsq,
+                                                       const uint32_t *__restrict__ pair_ref,
                                                        float *__restrict__ map, double *__restrict__ part, lvl_geom g,
                                                        uint32_t max_refs, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
 {
@@ -307,12 +316,12 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
         const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
         const size_t o = (size_t)Y * g.pitch + X;
 #pragma unroll
-        for (int c = 0; c < 3; c++) M[c][i] = img[sa + c * g.plane + o] * img[sb + c * g.plane + o];
+        for (int c = 0; c < 3; c++) M[c][i] = rimg[sa + c * g.plane + o] * img[sb + c * g.plane + o];
     }
     __syncthreads();
     const double val = (gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h)
-                           ? dssim_compare_stages<true>(M, T, mu, sq, map, g, sa, sb, p, x0, y0)
-                           : dssim_compare_stages<false>(M, T, mu, sq, map, g, sa, sb, p, x0, y0);
+                           ? dssim_compare_stages<true>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0)
+                           : dssim_compare_stages<false>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0);
     const double t = block_sum(val, s_red);
     if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
@@ -401,6 +410,11 @@ void ce_dssim_free(ce_batch *b)
     for (auto &p : b->ds_lin) hipFree(p), p = nullptr;
     for (auto &p : b->ds_tmp) hipFree(p), p = nullptr;
     hipFree(b->ds_img); hipFree(b->ds_mu); hipFree(b->ds_sq); hipFree(b->ds_i12); hipFree(b->ds_map);
+    for (int l = 0; l < CE_DSSIM_SCALES; l++) {
+        hipFree(b->ds_rimg[l]); hipFree(b->ds_rmu[l]); hipFree(b->ds_rsq[l]);
+        b->ds_rimg[l] = b->ds_rmu[l] = b->ds_rsq[l] = nullptr;
+    }
+    b->ds_ref_src = nullptr;
     hipFree(b->ds_part); hipFree(b->ds_level_scores);
     b->ds_img = b->ds_mu = b->ds_sq = b->ds_i12 = b->ds_map = nullptr;
     b->ds_part = b->ds_level_scores = nullptr;
@@ -434,6 +448,14 @@ static int dssim_allocate(ce_batch *b)
     CE_HIP(ctx, hipMalloc(&b->ds_img, slots * 3 * p0 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_mu, slots * 3 * p0 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_sq, slots * 3 * p0 * sizeof(float)));
+    // the references' planes, one set per level: they outlive the level loop (Dssim::create_image of the reference is
+    // run once per reference, dssim.rs:54-59; a reference handle keeps them across compares)
+    for (int l = 0; l < n; l++) {
+        const size_t rb = (size_t)b->max_refs * 3 * b->ds[l].plane * sizeof(float);
+        CE_HIP(ctx, hipMalloc(&b->ds_rimg[l], rb));
+        CE_HIP(ctx, hipMalloc(&b->ds_rmu[l], rb));
+        CE_HIP(ctx, hipMalloc(&b->ds_rsq[l], rb));
+    }
     CE_HIP(ctx, hipMalloc(&b->ds_map, (size_t)b->max_pairs * p0 * sizeof(float)));
     b->ds_blocks = ((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
@@ -462,6 +484,10 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     int rc = dssim_prepare(b);
     if (rc != CE_OK) return rc;
     const uint32_t n_slots = n_refs_used + n_pairs, mr = b->max_refs;
+    // reference handle (ce_ref_*): the references' img / mu / sq pyramid of an earlier launch is still valid
+    const bool cached = b->keep_ref_pyramid && b->ds_ref_src == d_refs && b->ds_ref_count >= n_refs_used;
+    const uint32_t z0 = cached ? n_refs_used : 0;
+    if (!cached) b->ref_builds[1]++;
     ds_geom g{};
     for (int l = 0; l < b->ds_levels; l++) {
         const auto &d = b->ds[l];
@@ -471,16 +497,17 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         const dim3 tiles((d.w + DT - 1) / DT, (d.h + DT - 1) / DT, 1);
         // create_image for every used slot (references once per reference)
         if (l == 0)
-            CE_LAUNCH(ctx, "dssim_create_u8", k_dssim_create<true>, dim3(tiles.x, tiles.y, n_slots), dim3(TPB), 0, d_refs, b->d_tests,
-                      ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_mu, b->ds_sq, lg, ng, has_next ? 1 : 0,
-                      b->img_bytes, n_refs_used, mr);
+            CE_LAUNCH(ctx, "dssim_create_u8", k_dssim_create<true>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
+                      ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_mu, b->ds_sq, b->ds_rimg[l], b->ds_rmu[l],
+                      b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         else
-            CE_LAUNCH(ctx, "dssim_create", k_dssim_create<false>, dim3(tiles.x, tiles.y, n_slots), dim3(TPB), 0, d_refs, b->d_tests,
-                      ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img, b->ds_mu, b->ds_sq, lg, ng,
-                      has_next ? 1 : 0, b->img_bytes, n_refs_used, mr);
+            CE_LAUNCH(ctx, "dssim_create", k_dssim_create<false>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
+                      ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img, b->ds_mu, b->ds_sq,
+                      b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         // compare per pair
         CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(tiles.x, tiles.y, n_pairs), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
-                  b->d_pair_ref, b->ds_map, b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
+                  (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
+                  b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
                   (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
         const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);
@@ -488,6 +515,10 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                   d.pitch, d.plane, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         g.npix[l] = d.w * d.h;
         g.nblk[l] = gp.x * gp.y;
+    }
+    if (b->keep_ref_pyramid && !cached) {
+        b->ds_ref_src = d_refs;
+        b->ds_ref_count = n_refs_used;
     }
     CE_LAUNCH(ctx, "dssim_finalize", k_dssim_finalize_pairs, dim3(n_pairs), dim3(64), 0, b->ds_part,
               b->ds_level_scores, b->d_scores, n_pairs, (uint32_t)b->ds_levels, b->ds_blocks, g);

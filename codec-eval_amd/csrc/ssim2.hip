@@ -875,6 +875,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     const bool cached = b->keep_ref_pyramid && b->ssim2_ref_src == d_refs && b->ssim2_ref_count >= n_refs_used &&
                         b->ssim2_ref_levels == std::min(b->n_scales, b->debug_max_scales);
     const uint32_t z0 = cached ? n_refs_used : 0;
+    if (!cached) b->ref_builds[0]++;
     using hblur_fn = void (*)(const float *, const uint32_t *, float *, uint32_t, uint32_t, uint32_t, size_t, uint32_t,
                               rg_consts, lvl_table, const uint2 *, const uint32_t *);
     using vblur_fn = void (*)(const float *, const float *, const uint32_t *, double *, uint32_t, uint32_t, uint32_t,

@@ -183,10 +183,12 @@ int ce_batch_butteraugli_pnorm3(ce_batch *b, uint32_t n_pairs, double *out);
 
 /* ---- reference handle: Ssimulacra2Reference::{new,compare} ------------------------
  * crates/codec-iter/src/eval.rs:138-149,83-89; crates/codec-compare/src/brute_force_sweep.rs:197-201,256
- * The handle keeps the reference resident in HBM together with its reference-side state: the XYB
- * roundtrip (CE_FLAG_XYB_ROUNDTRIP) and the SSIMULACRA2 XYB pyramid are built by the first compare and
- * reused by every later one.  The blurred reference planes are NOT kept: the blur passes are bound by
- * HBM traffic and a compare would read a cached plane just as it reads a recomputed one. */
+ * The handle keeps the reference resident in HBM together with its reference-side state for EVERY metric: the XYB
+ * roundtrip (CE_FLAG_XYB_ROUNDTRIP), the SSIMULACRA2 XYB pyramid, DSSIM's img / mu / blur(img^2) pyramid
+ * (Dssim::create_image of the reference) and Butteraugli's PsychoImage at both resolutions are built by the first
+ * compare that needs them and reused by every later one (Butteraugli's also depends on intensity_target: a compare
+ * with another target rebuilds it).  The row-blurred SSIMULACRA2 reference planes are NOT kept: the blur passes are
+ * bound by HBM traffic and a compare would read a cached plane just as it reads a recomputed one. */
 int ce_ref_create(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, uint32_t width, uint32_t height,
                   uint32_t flags, ce_ref **out);
 int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t metric_mask,
@@ -198,6 +200,9 @@ int ce_ref_compare(ce_ref *ref, const uint8_t *test, size_t test_len, uint32_t m
  * failures only. */
 int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *test_lens, uint32_t n_tests,
                         uint32_t metric_mask, float intensity_target, ce_scores *out);
+/* builds[k] = number of compares so far that had to (re)build the reference-side state of SSIMULACRA2 (k = 0),
+ * DSSIM (1), Butteraugli (2): 1 each after any number of compares of one handle with one intensity target */
+int ce_ref_stats(const ce_ref *ref, uint32_t builds[3]);
 void ce_ref_destroy(ce_ref *ref);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------ */

@@ -165,13 +165,15 @@ static float fast_log2f(float x)
     return yp / yq + (float)es;
 }
 
+extern int ceo_variant[CEO_V_COUNT]; /* sensitivity switches, all 0 by default (ce_oracle.h) */
+
 static float gamma_f(float v)
 {
     const float kRetMul = 19.245013259874995f * 0.693147180559945f;
     const float kRetAdd = -23.16046239805755f;
     if (v < 0.0f) v = 0.0f;
     const float biased = v + 9.9710635769299145f;
-    const float lg = fast_log2f(biased);
+    const float lg = ceo_variant[CEO_V_BA_LIBM_LOG2] ? log2f(biased) : fast_log2f(biased);
     return fmaf(kRetMul, lg, kRetAdd);
 }
 
@@ -416,6 +418,18 @@ static void malta_diff_map(const img *lum0, const img *lum1, double w_0gt1, doub
         const float scaler2 = norm2_0lt1 / ((float)norm1 + absval);
         const double fabs0 = fabs((double)v0);
         const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
+        if (ceo_variant[CEO_V_BA_MALTA_F32]) { /* the same four branches with f32 arithmetic */
+            const float fa = fabsf(v0), ts = 0.55f * fa, tb = 1.05f * fa;
+            if (v0 < 0) {
+                if (v1 > -ts) r = r - scaler2 * (v1 + ts);
+                else if (v1 < -tb) r = r + scaler2 * (-v1 - tb);
+            } else {
+                if (v1 < ts) r = r + scaler2 * (ts - v1);
+                else if (v1 > tb) r = r - scaler2 * (v1 - tb);
+            }
+            diffs.p[k] = r;
+            continue;
+        }
         if (v0 < 0) {
             if (v1 > -too_small) {
                 double impact = scaler2 * (v1 + too_small);

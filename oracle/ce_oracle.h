@@ -44,6 +44,24 @@ enum {
     CEO_BACKEND = 4
 };
 
+/* ---- sensitivity switches (tests/golden/sensitivity.py ONLY) ---------------------------------------------------
+ * The SSIMULACRA2 / DSSIM / Butteraugli restatements make choices the absent crates could make differently
+ * (DESIGN.md §2 lists them).  Each switch flips ONE such choice so that its effect on the score can be measured;
+ * 0 (the default) is the restatement every test and the device are held to.  Process-global, not thread safe. */
+enum ceo_variant_key {
+    CEO_V_SSIM2_SRGB_F32_POWF = 0, /* sRGB->linear table by f32 powf instead of f64 pow rounded once */
+    CEO_V_SSIM2_HOST_CBRTF = 1,    /* host libm cbrtf instead of the msun two-Halley-steps form */
+    CEO_V_SSIM2_IIR_NO_FMA = 2,    /* recursion with separate multiply and add (blur_mode 1 only) */
+    CEO_V_DSSIM_LAB_NO_FMA = 3,    /* RGB -> XYZ / Lab affine steps with separate multiply and add */
+    CEO_V_DSSIM_F32_FINAL = 4,     /* per-scale scores, weighting and 1/ssim - 1 in f32, widened at the end */
+    CEO_V_BA_MALTA_F32 = 5,        /* Malta asymmetry term in f32 instead of f64 */
+    CEO_V_BA_LIBM_LOG2 = 6,        /* libm log2f instead of the lineage's FastLog2f in Gamma() */
+    CEO_V_SSIM2_F32_POOL = 7,      /* per-pixel map terms summed in f32 per row before the f64 pool */
+    CEO_V_COUNT = 8
+};
+void ceo_set_variant(int key, int value);
+int ceo_get_variant(int key);
+
 /* ---- PSNR: src/metrics/mod.rs:312-331 ---------------------------------- */
 int ceo_psnr(const uint8_t *ref, size_t ref_len, const uint8_t *test, size_t test_len,
              size_t width, size_t height, double *out);

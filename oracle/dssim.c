@@ -71,18 +71,29 @@ static float cbrt_poly(float x)
 #define LAB_EPSILON (216.0f / 24389.0f)
 #define LAB_K (24389.0f / (27.0f * 116.0f))
 
+extern int ceo_variant[CEO_V_COUNT]; /* sensitivity switches, all 0 by default (ce_oracle.h) */
+
 /* linear RGB -> normalised (L, a, b), each in ~[0,1] */
 static void rgb_to_lab(float r, float g, float b, float *L, float *A, float *B)
 {
     float fx = fmaf(b, 0.1805f / D65X, fmaf(g, 0.3576f / D65X, r * (0.4124f / D65X)));
     float fy = fmaf(b, 0.0722f / D65Y, fmaf(g, 0.7152f / D65Y, r * (0.2126f / D65Y)));
     float fz = fmaf(b, 0.9505f / D65Z, fmaf(g, 0.1192f / D65Z, r * (0.0193f / D65Z)));
+    if (ceo_variant[CEO_V_DSSIM_LAB_NO_FMA]) {
+        fx = (r * (0.4124f / D65X) + g * (0.3576f / D65X)) + b * (0.1805f / D65X);
+        fy = (r * (0.2126f / D65Y) + g * (0.7152f / D65Y)) + b * (0.0722f / D65Y);
+        fz = (r * (0.0193f / D65Z) + g * (0.1192f / D65Z)) + b * (0.9505f / D65Z);
+    }
     float X = fx > LAB_EPSILON ? cbrt_poly(fx) - 16.0f / 116.0f : LAB_K * fx;
     float Y = fy > LAB_EPSILON ? cbrt_poly(fy) - 16.0f / 116.0f : LAB_K * fy;
     float Z = fz > LAB_EPSILON ? cbrt_poly(fz) - 16.0f / 116.0f : LAB_K * fz;
     *L = Y * 1.05f;
     *A = fmaf(500.0f / 220.0f, X - Y, 86.2f / 220.0f);
     *B = fmaf(200.0f / 220.0f, Y - Z, 107.9f / 220.0f);
+    if (ceo_variant[CEO_V_DSSIM_LAB_NO_FMA]) {
+        *A = (500.0f / 220.0f) * (X - Y) + 86.2f / 220.0f;
+        *B = (200.0f / 220.0f) * (Y - Z) + 107.9f / 220.0f;
+    }
 }
 
 typedef struct {
@@ -216,6 +227,11 @@ static double compare(const dssim_image *o, const dssim_image *m, double *scale_
     }
     if (n_scales) *n_scales = ns;
     double ssim = ssim_sum / weight_sum;
+    if (ceo_variant[CEO_V_DSSIM_F32_FINAL]) { /* the crate's Val as f32: weighting and to_dssim in f32, widened by f64::from */
+        float s = (float)ssim_sum / (float)weight_sum;
+        if (!(s > FLT_EPSILON)) s = FLT_EPSILON;
+        return (double)(1.0f / s - 1.0f);
+    }
     if (!(ssim > DBL_EPSILON)) ssim = DBL_EPSILON;
     return 1.0 / ssim - 1.0; /* to_dssim */
 }

@@ -44,6 +44,9 @@ def lib() -> C.CDLL:
         _lib.ceo_rgb8_to_dssim_image.argtypes = [u8p, sz, f32p]
         _lib.ceo_rgb8_to_dssim_image.restype = None
         _lib.ceo_xyb_roundtrip.argtypes = [u8p, sz, sz, sz, u8p]
+        _lib.ceo_set_variant.argtypes = [C.c_int, C.c_int]
+        _lib.ceo_set_variant.restype = None
+        _lib.ceo_get_variant.argtypes = [C.c_int]
         _lib.ceo_cbrtf_compare.argtypes = [f32p, sz, f32p, f32p]
         _lib.ceo_cbrtf_compare.restype = None
         _lib.ceo_ssimulacra2.argtypes = [u8p, sz, u8p, sz, sz, sz, C.c_int, f64p]
@@ -103,6 +106,19 @@ def sse(ref, test) -> int:
 
 def srgb_u8_to_linear(v: int) -> float:
     return float(lib().ceo_srgb_u8_to_linear(int(v)))
+
+
+VARIANTS = {"ssim2_srgb_f32_powf": 0, "ssim2_host_cbrtf": 1, "ssim2_iir_no_fma": 2, "dssim_lab_no_fma": 3,
+            "dssim_f32_final": 4, "ba_malta_f32": 5, "ba_libm_log2": 6, "ssim2_f32_pool": 7}
+
+
+def set_variant(name: str, value: int):
+    """Sensitivity switch of ce_oracle.h (tests/golden/sensitivity.py only; 0 = the restatement)."""
+    lib().ceo_set_variant(VARIANTS[name], int(value))
+
+
+def variants_all_default() -> bool:
+    return all(lib().ceo_get_variant(k) == 0 for k in VARIANTS.values())
 
 
 def cbrtf_compare(x) -> tuple:

@@ -24,6 +24,11 @@
 
 #include <math.h>
 
+/* sensitivity switches (ce_oracle.h): all 0 unless tests/golden/sensitivity.py sets one */
+int ceo_variant[CEO_V_COUNT];
+void ceo_set_variant(int key, int value) { if (key >= 0 && key < CEO_V_COUNT) ceo_variant[key] = value; }
+int ceo_get_variant(int key) { return key >= 0 && key < CEO_V_COUNT ? ceo_variant[key] : 0; }
+
 /* ---------------------------------------------------------------- PSNR ---- */
 
 /* src/metrics/mod.rs:316-322 — the loop sums (r-t)^2 in f64.  Every partial sum

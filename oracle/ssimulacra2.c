@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+extern int ceo_variant[CEO_V_COUNT]; /* sensitivity switches, all 0 by default (ce_oracle.h) */
 #define NUM_SCALES 6
 #define BLUR_RADIUS 5 /* round(3.2795*1.5 + 0.2546) */
 
@@ -33,6 +34,10 @@ void ceo_ssim2_srgb_lut(float lut[256])
         double v = (double)i / 255.0;
         double l = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4);
         lut[i] = (float)l;
+        if (ceo_variant[CEO_V_SSIM2_SRGB_F32_POWF]) {
+            float vf = (float)i / 255.0f;
+            lut[i] = vf <= 0.04045f ? vf / 12.92f : powf((vf + 0.055f) / 1.055f, 2.4f);
+        }
     }
 }
 
@@ -76,6 +81,7 @@ static float ssim2_cbrtf(float x)
     fx.f = x;
     uint32_t hx = fx.u & 0x7fffffffu;
     if (hx == 0) return x;
+    if (ceo_variant[CEO_V_SSIM2_HOST_CBRTF]) return cbrtf(x);
     if (hx < 0x00800000u) { /* subnormal */
         t.u = 0x4b800000u;
         t.f *= x;
@@ -209,6 +215,15 @@ static void rg_line_iir(const rg_coeffs *rg, const float *in, float *out, ptrdif
         float o[3];
         for (int k = 0; k < 3; k++) {
             float v = sum * mul_in[k];
+            if (ceo_variant[CEO_V_SSIM2_IIR_NO_FMA]) {
+                v = v - prev2[k];
+                prev2[k] = prev[k];
+                float t = mul_prev[k] * prev[k];
+                v = t + v;
+                prev[k] = v;
+                o[k] = v;
+                continue;
+            }
             v = fmaf(-1.0f, prev2[k], v);
             prev2[k] = prev[k];
             v = fmaf(mul_prev[k], prev[k], v);
@@ -276,6 +291,7 @@ static void ssim_map(size_t w, size_t h, const float *m1, const float *m2, const
             float num_s = fmaf(2.0f, s12[o + i] - mu12, C2);
             float denom_s = (s11[o + i] - mu11) + (s22[o + i] - mu22) + C2;
             double d = 1.0 - (double)((num_m * num_s) / denom_s);
+            if (ceo_variant[CEO_V_SSIM2_F32_POOL]) d = (double)(1.0f - (num_m * num_s) / denom_s);
             if (!(d > 0.0)) d = 0.0;
             sum1[0] += d;
             double d2 = d * d;
@@ -298,6 +314,8 @@ static void edge_diff_map(size_t w, size_t h, const float *img1, const float *mu
         for (size_t i = 0; i < n; i++) {
             double d1 = (1.0 + (double)fabsf(img2[o + i] - mu2[o + i])) /
                             (1.0 + (double)fabsf(img1[o + i] - mu1[o + i])) - 1.0;
+            if (ceo_variant[CEO_V_SSIM2_F32_POOL])
+                d1 = (double)((1.0f + fabsf(img2[o + i] - mu2[o + i])) / (1.0f + fabsf(img1[o + i] - mu1[o + i])) - 1.0f);
             double artifact = d1 > 0.0 ? d1 : 0.0;
             double detail_lost = -d1 > 0.0 ? -d1 : 0.0;
             sum1[0] += artifact;

@@ -32,7 +32,26 @@ CASES = [  # name, w, h, seed, kind, quality, 4:2:0
 ]
 
 
+def dump_raw(arrays):
+    """The same inputs as packed RGB8 files + a manifest, for readers without an npz parser
+    (bindings/rust/pin-fixtures reads these and prints the CRATES' scores: tests/test_crate_pin.py)."""
+    raw = os.path.join(HERE, "raw")
+    os.makedirs(raw, exist_ok=True)
+    names = sorted({k.rsplit(".", 1)[0] for k in arrays})
+    with open(os.path.join(raw, "manifest.tsv"), "w") as f:
+        f.write("# name\twidth\theight   (files: <name>.ref.rgb, <name>.test.rgb; packed RGB8, row-major)\n")
+        for n in names:
+            h, w, _ = arrays[n + ".ref"].shape
+            f.write(f"{n}\t{w}\t{h}\n")
+            for side in ("ref", "test"):
+                arrays[f"{n}.{side}"].astype(np.uint8).tofile(os.path.join(raw, f"{n}.{side}.rgb"))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--raw-only":  # re-dump tests/golden/raw/ from the committed inputs.npz
+        d = np.load(os.path.join(HERE, "inputs.npz"))
+        dump_raw({k: d[k] for k in d.files})
+        return
     arrays, scores = {}, {}
     for name, w, h, seed, kind, q, s420 in CASES:
         ref = wl.make_reference(w, h, seed, kind)
@@ -55,6 +74,7 @@ def main():
             "ssimulacra2_xyb_ref": O.ssimulacra2(rt, test, w, h, 1),
         }
     np.savez_compressed(os.path.join(HERE, "inputs.npz"), **arrays)
+    dump_raw(arrays)
     with open(os.path.join(HERE, "scores.json"), "w") as f:
         json.dump(scores, f, indent=1, sort_keys=True)
     print("wrote", len(CASES), "cases")

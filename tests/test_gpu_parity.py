@@ -338,9 +338,14 @@ def test_reference_handle_sweep_and_cached_reference_side(gpu_ctx, oracle, ce, w
     cfg = ce.MetricConfig.all()
     for rt in (False, True):
         hd = ce.ReferenceHandle(gpu_ctx, ref, w, h, xyb_roundtrip=rt)
-        first = hd.compare(tests[0], cfg)  # builds the reference side
-        many = hd.compare_many(tests, cfg)  # grows the handle to 5 slots, reuses nothing stale
-        again = hd.compare_many(tests[::-1], cfg)[::-1]  # reference side now cached
+        assert hd.stats() == (0, 0, 0)
+        first = hd.compare(tests[0], cfg)  # builds the reference side of every metric
+        assert hd.stats() == (1, 1, 1)
+        assert hd.compare(tests[1], cfg).dssim > 0 and hd.stats() == (1, 1, 1)  # ... once: this compare built nothing
+        many = hd.compare_many(tests, cfg)  # grows the handle to 5 slots (a new batch: one rebuild), reuses nothing stale
+        assert hd.stats() == (2, 2, 2)
+        again = hd.compare_many(tests[::-1], cfg)[::-1]  # reference side cached: XYB roundtrip, SSIMULACRA2 XYB pyramid,
+        assert hd.stats() == (2, 2, 2)                   # DSSIM img / mu / sq pyramid, Butteraugli PsychoImage
         full = cfg.with_xyb_roundtrip() if rt else cfg
         for t, m, a in zip(tests, many, again):
             fresh = gpu_ctx.calculate_metrics(ref, t, w, h, full)
@@ -352,6 +357,15 @@ def test_reference_handle_sweep_and_cached_reference_side(gpu_ctx, oracle, ce, w
         res = hd.compare_many([tests[1], ref[:7], tests[2]], cfg)
         assert isinstance(res[1], ce.DimensionMismatch)
         assert res[0].ssimulacra2 == many[1].ssimulacra2 and res[2].ssimulacra2 == many[2].ssimulacra2
+        # Butteraugli's reference side depends on the intensity target: another target rebuilds it (and only it), and
+        # the result equals a fresh evaluation with that target
+        before = hd.stats()
+        dim = hd.compare(tests[2], ce.MetricConfig(butteraugli=True), intensity_target=250.0)
+        assert hd.stats() == (before[0], before[1], before[2] + 1)
+        if not rt:
+            assert dim.butteraugli == gpu_ctx.calculate_butteraugli_with_intensity(ref, tests[2], w, h, 250.0)
+        back = hd.compare(tests[2], cfg)
+        assert back.butteraugli == many[2].butteraugli and hd.stats()[2] == before[2] + 2
         hd.close()
     # against the oracle too (no roundtrip)
     hd = ce.ReferenceHandle(gpu_ctx, ref, w, h)
