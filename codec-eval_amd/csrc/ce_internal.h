@@ -120,6 +120,7 @@ struct ce_batch {
     uint32_t work_len_h = 0, work_len_v = 0, work_cap_h = 0, work_cap_v = 0, work_version = ~0u, work_pairs = 0;
     uint32_t work_len_ht = 0, work_len_vt = 0, work_cap_ht = 0, work_cap_vt = 0, work_version_t = ~0u, work_pairs_t = 0;
     uint32_t work_blk_ht = 0, work_blk_vt = 0;
+    std::vector<uint2> work_chunks_h, work_chunks_v;  // (offset, length) segments of the level-0 lists (CE_SSIM2_L0_CHUNK experiment)
     // reference handles (ce_ref_*): the references' XYB pyramid of the last SSIMULACRA2 run stays valid
     // until a reference is replaced, so later compares only build the distorted side
     bool keep_ref_pyramid = false;

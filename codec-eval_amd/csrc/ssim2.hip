@@ -16,6 +16,7 @@
 // NOT negligible at the score level (DESIGN.md "Why the recursive form is kept").
 // Build with -ffp-contract=off: every fused multiply-add below is explicit.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ce_internal.h"
 
@@ -795,24 +796,39 @@ int ce_ssim2_prepare(ce_batch *b)
 // reference's planes are then fetched from HBM once per reference, not once per pair.  The list is built on the
 // host whenever the pair -> reference table changes: keys (reference, channel, block) are dealt to the 8 classes
 // in turn, each key followed by all the pairs of that reference; entry id = slot * 8 + class.
-static int build_one_list(ce_batch *b, uint32_t n_pairs, uint32_t n_blocks, uint2 **d_list, uint32_t *len, uint32_t *cap)
+// chunk_pairs > 0 (experiment, CE_SSIM2_L0_CHUNK): the list is cut into segments of whole references holding at most
+// that many pairs; `chunks` receives (offset, length) of each segment and every segment is launched on its own
+// (row pass then column pass of one segment back to back, so that the intermediate of a segment is still in the
+// Infinity Cache when its column pass reads it).
+static int build_one_list(ce_batch *b, uint32_t n_pairs, uint32_t n_blocks, uint2 **d_list, uint32_t *len, uint32_t *cap,
+                          uint32_t chunk_pairs = 0, std::vector<uint2> *chunks = nullptr)
 {
     ce_ctx *ctx = b->ctx;
     std::vector<std::vector<uint32_t>> pairs_of(b->max_refs);
     for (uint32_t p = 0; p < n_pairs; p++) pairs_of[b->h_pair_ref[p]].push_back(p);
-    std::vector<uint2> cls[8];
-    uint32_t k = 0;
-    for (uint32_t r = 0; r < b->max_refs; r++) {
-        if (pairs_of[r].empty()) continue;
-        for (uint32_t c = 0; c < 3; c++)
-            for (uint32_t bx = 0; bx < n_blocks; bx++, k++)
-                for (uint32_t p : pairs_of[r]) cls[k & 7].push_back(make_uint2(bx | (c << 16), p));
+    std::vector<uint2> flat;
+    if (chunks) chunks->clear();
+    uint32_t r = 0;
+    while (r < b->max_refs) {
+        std::vector<uint2> cls[8];
+        uint32_t k = 0, in_chunk = 0;
+        for (; r < b->max_refs; r++) {
+            if (pairs_of[r].empty()) continue;
+            if (chunk_pairs && in_chunk && in_chunk + pairs_of[r].size() > chunk_pairs) break;
+            in_chunk += (uint32_t)pairs_of[r].size();
+            for (uint32_t c = 0; c < 3; c++)
+                for (uint32_t bx = 0; bx < n_blocks; bx++, k++)
+                    for (uint32_t p : pairs_of[r]) cls[k & 7].push_back(make_uint2(bx | (c << 16), p));
+        }
+        size_t longest = 0;
+        for (auto &v : cls) longest = std::max(longest, v.size());
+        if (longest == 0) continue;
+        const size_t base = flat.size();
+        flat.resize(base + longest * 8, make_uint2(~0u, 0u));
+        for (uint32_t x = 0; x < 8; x++)
+            for (size_t sl = 0; sl < cls[x].size(); sl++) flat[base + sl * 8 + x] = cls[x][sl];
+        if (chunks) chunks->push_back(make_uint2((uint32_t)base, (uint32_t)(longest * 8)));
     }
-    size_t longest = 0;
-    for (auto &v : cls) longest = std::max(longest, v.size());
-    std::vector<uint2> flat(longest * 8, make_uint2(~0u, 0u));
-    for (uint32_t x = 0; x < 8; x++)
-        for (size_t sl = 0; sl < cls[x].size(); sl++) flat[sl * 8 + x] = cls[x][sl];
     if (flat.size() > *cap) {
         if (*d_list) CE_HIP(ctx, hipFree(*d_list));
         *d_list = nullptr;
@@ -825,6 +841,15 @@ static int build_one_list(ce_batch *b, uint32_t n_pairs, uint32_t n_blocks, uint
     return CE_OK;
 }
 
+static uint32_t ssim2_l0_chunk()
+{
+    static const uint32_t v = [] {
+        const char *e = std::getenv("CE_SSIM2_L0_CHUNK");
+        return e ? (uint32_t)std::max(0, std::atoi(e)) : 0u;
+    }();
+    return v;
+}
+
 static int build_work_lists(ce_batch *b, uint32_t n_pairs, uint32_t hblk, uint32_t vblk)
 {
     if (b->work_version == b->pair_ref_version && b->work_pairs == n_pairs && b->d_work_h) return CE_OK;
@@ -832,9 +857,9 @@ static int build_work_lists(ce_batch *b, uint32_t n_pairs, uint32_t hblk, uint32
         b->ctx->err = "SSIMULACRA2: image too large for the block index of the work list";
         return CE_ERR_INVALID_ARG;
     }
-    int rc = build_one_list(b, n_pairs, hblk, &b->d_work_h, &b->work_len_h, &b->work_cap_h);
+    int rc = build_one_list(b, n_pairs, hblk, &b->d_work_h, &b->work_len_h, &b->work_cap_h, ssim2_l0_chunk(), &b->work_chunks_h);
     if (rc != CE_OK) return rc;
-    rc = build_one_list(b, n_pairs, vblk, &b->d_work_v, &b->work_len_v, &b->work_cap_v);
+    rc = build_one_list(b, n_pairs, vblk, &b->d_work_v, &b->work_len_v, &b->work_cap_v, ssim2_l0_chunk(), &b->work_chunks_v);
     if (rc != CE_OK) return rc;
     b->work_version = b->pair_ref_version;
     b->work_pairs = n_pairs;
@@ -918,12 +943,30 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             }
             rc = build_work_lists(b, n_pairs, hblk, vblk);
             if (rc != CE_OK) return rc;
+            if (ssim2_l0_chunk() && b->work_chunks_h.size() > 1 && s0 != ctx->stream && b->ev_done[2]) {
+                // experiment: segment by segment on two alternating streams (row pass, then column pass of the same segment)
+                if (!b->lvl_stream[1]) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[1], hipStreamNonBlocking));
+                CE_HIP(ctx, hipStreamWaitEvent(b->lvl_stream[1], b->ev_prep[0], 0));
+                for (size_t ck = 0; ck < b->work_chunks_h.size(); ck++) {
+                    hipStream_t sc = (ck & 1) ? b->lvl_stream[1] : s0;
+                    const uint2 ch = b->work_chunks_h[ck], cv = b->work_chunks_v[ck];
+                    CE_LAUNCH_ON(ctx, sc, "ssim2_hblur_L0", h_l0, dim3(ch.y), dim3(HB_THREADS), 0, b->d_xyb[0], b->d_pair_ref,
+                                 b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab, (const uint2 *)b->d_work_h + ch.x,
+                                 (const uint32_t *)b->d_pair_first);
+                    CE_LAUNCH_ON(ctx, sc, "ssim2_vblur_ssim_L0", v_l0, dim3(cv.y), dim3(64), 0, b->d_hbuf[0], b->d_xyb[0],
+                                 b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab,
+                                 (const uint2 *)b->d_work_v + cv.x, (const uint32_t *)b->d_pair_first);
+                }
+                CE_HIP(ctx, hipEventRecord(b->ev_done[2], b->lvl_stream[1]));
+                CE_HIP(ctx, hipStreamWaitEvent(s0, b->ev_done[2], 0));
+            } else {
             CE_LAUNCH_ON(ctx, s0, "ssim2_hblur_L0", h_l0, dim3(b->work_len_h), dim3(HB_THREADS), 0, b->d_xyb[0], b->d_pair_ref,
                          b->d_hbuf[0], d.w, d.h, d.pitch, d.plane, b->max_refs, rg, tab, (const uint2 *)b->d_work_h,
                          (const uint32_t *)b->d_pair_first);
             CE_LAUNCH_ON(ctx, s0, "ssim2_vblur_ssim_L0", v_l0, dim3(b->work_len_v), dim3(64), 0, b->d_hbuf[0], b->d_xyb[0],
                          b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab,
                          (const uint2 *)b->d_work_v, (const uint32_t *)b->d_pair_first);
+            }
             if (s0 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[0], s0));
         } else {
             const uint32_t l = tab.n++;

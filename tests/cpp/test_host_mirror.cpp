@@ -5,8 +5,10 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "codec_eval.hpp"
+#include "codec_eval_multi.hpp"
 
 using namespace codec_eval;
 using eval::ImageData;
@@ -62,6 +64,133 @@ static void host_only()
             threw = e.kind == Error::Kind::MetricCalculation;
         }
         CHECK(threw);
+    }
+}
+
+// ---- one process, N devices: the queue and the ordering, with the device count and the scorer mocked -------------
+static void multi_device_host_logic()
+{
+    using eval::GuidedQueue;
+    using eval::ReferenceJob;
+    // guided self-scheduling: chunks shrink as the queue drains, every index is handed out exactly once, in order
+    {
+        std::vector<size_t> order(40), cost(40, 10);
+        for (size_t i = 0; i < 40; i++) order[i] = i;
+        GuidedQueue q(order, cost, 4, 0);
+        std::vector<size_t> sizes, seen;
+        for (;;) {
+            const auto c = q.pull();
+            if (c.empty()) break;
+            sizes.push_back(c.size());
+            seen.insert(seen.end(), c.begin(), c.end());
+        }
+        CHECK(seen == order);
+        CHECK(sizes.front() == 5 && sizes.back() == 1);  // 40 / (2 * 4) first, single references at the end
+        for (size_t i = 1; i < sizes.size(); i++) CHECK(sizes[i] <= sizes[i - 1]);
+        CHECK(q.pull().empty());
+    }
+    {  // a device-memory budget caps a pull; a single job larger than the budget still goes out alone
+        GuidedQueue q({0, 1, 2, 3, 4, 5, 6, 7}, {50, 50, 50, 500, 50, 50, 50, 50}, 1, 120);
+        CHECK((q.pull() == std::vector<size_t>{0, 1}));
+        CHECK((q.pull() == std::vector<size_t>{2}));     // wants 3, but 2 + 3 would not fit
+        CHECK((q.pull() == std::vector<size_t>{3}));     // over budget on its own: alone
+        CHECK((q.pull() == std::vector<size_t>{4, 5}));
+    }
+    CHECK((eval::largest_first({5, 9, 5, 1}) == std::vector<size_t>{1, 0, 2, 3}));
+    // the pool with 3 mock devices: results land in the job's own slots whatever device scored it, the work is spread,
+    // and a failing device stops the run with an error
+    std::vector<std::vector<uint8_t>> pixels;
+    std::vector<ReferenceJob> jobs(23);
+    for (size_t i = 0; i < jobs.size(); i++) {
+        pixels.emplace_back(4, (uint8_t)i);
+        jobs[i].reference = pixels.back().data();
+        jobs[i].width = 8 + (uint32_t)(i % 5);
+        jobs[i].height = 8;
+        jobs[i].tests.assign(1 + i % 4, pixels.back().data());
+    }
+    auto scorer = [](int worker, std::vector<ReferenceJob *> &chunk) {
+        for (ReferenceJob *j : chunk)
+            for (size_t t = 0; t < j->tests.size(); t++) {
+                j->scores[t].psnr = 1000.0 * j->reference[0] + (double)t;  // a value that identifies (job, test)
+                j->scores[t].valid = CE_METRIC_PSNR;
+            }
+        std::this_thread::sleep_for(std::chrono::milliseconds(2 + worker));  // uneven devices
+        return (int)CE_OK;
+    };
+    eval::DevicePool pool(3, scorer);
+    CHECK(pool.devices() == 3);
+    const eval::MultiDeviceStats st = pool.run(jobs, MetricConfig::fast());
+    size_t total = 0;
+    for (size_t d = 0; d < 3; d++) {
+        total += st.jobs_per_device[d];
+        CHECK(st.jobs_per_device[d] > 0 && st.pulls_per_device[d] > 0);
+    }
+    CHECK(total == jobs.size());
+    for (size_t i = 0; i < jobs.size(); i++) {
+        CHECK(jobs[i].device >= 0 && jobs[i].device < 3 && jobs[i].scores.size() == 1 + i % 4);
+        for (size_t t = 0; t < jobs[i].scores.size(); t++) CHECK(jobs[i].scores[t].psnr == 1000.0 * (double)i + (double)t);
+    }
+    eval::DevicePool one(1, scorer);  // the same jobs on one device: identical results
+    std::vector<ReferenceJob> again = jobs;
+    one.run(again, MetricConfig::fast());
+    for (size_t i = 0; i < jobs.size(); i++)
+        for (size_t t = 0; t < jobs[i].scores.size(); t++) CHECK(again[i].scores[t].psnr == jobs[i].scores[t].psnr);
+    eval::DevicePool bad(2, [](int, std::vector<ReferenceJob *> &chunk) {  // whichever device meets job 7 fails
+        for (ReferenceJob *j : chunk)
+            if (j->reference[0] == 7) return (int)CE_ERR_BACKEND;
+        return (int)CE_OK;
+    });
+    bool threw = false;
+    try {
+        bad.run(jobs, MetricConfig::fast());
+    } catch (const Error &e) {
+        threw = e.kind == Error::Kind::MetricCalculation;
+    }
+    CHECK(threw);
+}
+
+// the multi-device session on the devices that exist: every report equals the single-device session's, in input order
+static void multi_device_on_gpu(const std::shared_ptr<HipBackend> &be)
+{
+    auto pool = std::make_shared<eval::DevicePool>();  // every visible device
+    CHECK(pool->devices() == HipBackend::device_count() && pool->devices() >= 1);
+    eval::EvalConfig cfg;
+    cfg.metrics = MetricConfig::all();
+    cfg.quality_levels = {40.0, 70.0, 90.0};
+    int step = 1;
+    size_t dec_w = 0, dec_h = 0;
+    auto encode = [&](const ImageData &im, const eval::EncodeRequest &rq) {
+        step = 1 + (int)((100.0 - rq.quality) / 8.0);
+        dec_w = im.width, dec_h = im.height;
+        return im.to_rgb8_vec();
+    };
+    auto decode = [&](const std::vector<uint8_t> &bytes) {
+        std::vector<uint8_t> d(bytes);
+        for (auto &v : d) v = (uint8_t)std::min(255, (v / step) * step + step / 2);
+        return ImageData::rgb(std::move(d), dec_w, dec_h);
+    };
+    eval::MultiDeviceEvalSession multi(pool, cfg);
+    multi.add_codec_with_decode("toy", "1.0", encode, decode).add_codec("size-only", "0.1", encode);
+    eval::EvalSession single(be, cfg);
+    single.add_codec_with_decode("toy", "1.0", encode, decode).add_codec("size-only", "0.1", encode);
+    std::vector<std::pair<std::string, ImageData>> corpus;
+    const size_t shapes[5][2] = {{96, 80}, {64, 64}, {96, 80}, {120, 40}, {64, 64}};  // mixed shapes, repeated shapes
+    for (size_t i = 0; i < 5; i++) corpus.emplace_back("img" + std::to_string(i) + ".png", create_test_image(shapes[i][0], shapes[i][1], (uint8_t)(11 * i)));
+    eval::MultiDeviceStats st;
+    const std::vector<eval::ImageReport> reports = multi.evaluate_corpus(corpus, &st);
+    CHECK(reports.size() == corpus.size());
+    size_t scored = 0;
+    for (size_t d = 0; d < st.jobs_per_device.size(); d++) scored += st.jobs_per_device[d];
+    CHECK(scored == corpus.size());
+    for (size_t i = 0; i < corpus.size(); i++) {
+        const eval::ImageReport want = single.evaluate_image(corpus[i].first, corpus[i].second);
+        CHECK(reports[i].name == want.name && reports[i].results.size() == want.results.size() && reports[i].results.size() == 6);
+        for (size_t k = 0; k < want.results.size(); k++) {
+            const eval::CodecResult &a = reports[i].results[k], &b = want.results[k];
+            CHECK(a.codec_id == b.codec_id && a.quality == b.quality && a.file_size == b.file_size);
+            CHECK(a.metrics.psnr == b.metrics.psnr && a.metrics.ssimulacra2 == b.metrics.ssimulacra2 && a.metrics.dssim == b.metrics.dssim &&
+                  a.metrics.butteraugli == b.metrics.butteraugli && a.perception == b.perception);  // bit for bit
+        }
     }
 }
 
@@ -199,12 +328,14 @@ static void with_gpu()
         named = std::string(e.what()).find("SSIM2 error for pattern.png q75: ") == 0;
     }
     CHECK(named);
+    multi_device_on_gpu(be);
 }
 
 int main(int argc, char **argv)
 {
     const bool gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
     host_only();
+    multi_device_host_logic();
     if (gpu) with_gpu();
     std::printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", g_fail);
     return g_fail ? 1 : 0;

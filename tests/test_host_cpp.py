@@ -15,7 +15,7 @@ def _build(ce, tmp_path):
         "g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror",
         "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "codec-eval_amd", "host"),
         os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"), "-o", exe,
-        "-L", libdir, "-lce_metrics_hip", f"-Wl,-rpath,{libdir}",
+        "-L", libdir, "-lce_metrics_hip", f"-Wl,-rpath,{libdir}", "-pthread",
     ])
     return exe
 
