@@ -180,7 +180,7 @@ def main():
     # One context (= one HIP stream family) per batch, so the buckets' kernel chains overlap on the GPU.  depth > 1 keeps
     # that many sets of batches in flight (step k is launched before step k-1's scores are collected, the way a session
     # streams a corpus larger than one batch); every timed step's scores are still collected inside the timed region.
-    depth = args.depth if args.depth > 0 else 2
+    depth = 1 if args.serial else (args.depth if args.depth > 0 else 2)
     sets = []
     for _ in range(depth):
         bs = []
@@ -206,6 +206,13 @@ def main():
 
     def run_steps(n, only_cfg=None):
         out = None
+        if args.serial:  # one batch at a time, collected before the next is launched: nothing overlaps, across contexts either
+            for k in range(n):
+                out = []
+                for g, c, _, b in sets[0]:
+                    b.launch(len(g.pairs), only_cfg or c)
+                    out.append(b.collect(len(g.pairs)))
+            return out
         for k in range(n):
             launch(k, only_cfg)
             if k >= depth - 1:

@@ -223,11 +223,11 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
 template <int LEN>
 __global__ __launch_bounds__(TPB) void k_ba_blur_v(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
                                                    plane_sel so, blur_kernel bk, float inv_wsum, uint32_t n_refs_used,
-                                                   uint32_t max_refs, int by_slot)
+                                                   uint32_t max_refs, int by_slot, uint32_t z0)
 {
     constexpr int off = LEN / 2, TW = 64, TR = 32, RAW = TR + LEN - 1;
     __shared__ float tile[RAW * TW];
-    const uint32_t u = blockIdx.z / si.n, k = blockIdx.z % si.n;
+    const uint32_t u = blockIdx.z / si.n + z0, k = blockIdx.z % si.n;
     const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
     const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
@@ -591,7 +591,32 @@ __device__ constexpr mline MALTA_LF[16] = {
     {5, {{2, -4}, {1, -2}, {0, 0}, {-1, 2}, {-2, 4}}},
 };
 
-constexpr int MT = 64, MH = 4, ML = MT + 2 * MH;  // 64x64 outputs per block from a zero-padded 72x72 LDS tile (1.27x halo)
+// 64 x 32 outputs per block from a zero-padded 72 x 40 LDS tile of (x, y) pairs (1.41x halo)
+constexpr int MT = 64, MR = 32, MH = 4, ML = MT + 2 * MH, MLR = MR + 2 * MH;
+
+// a Malta line whose taps run from the bottom row to the top one (every other line runs top to bottom)
+__device__ constexpr bool malta_line_descends(const mline &ln)
+{
+    for (int j = 1; j < ln.n; j++)
+        if (ln.d[j][1] > ln.d[j - 1][1]) return false;
+    return ln.d[0][1] != ln.d[ln.n - 1][1];
+}
+__device__ constexpr bool malta_line_monotone(const mline &ln)
+{
+    bool up = true, down = true;
+    for (int j = 1; j < ln.n; j++) {
+        if (ln.d[j][1] < ln.d[j - 1][1]) up = false;
+        if (ln.d[j][1] > ln.d[j - 1][1]) down = false;
+    }
+    return up || down;
+}
+__device__ constexpr bool malta_tables_monotone()
+{
+    for (int k = 0; k < 16; k++)
+        if (!malta_line_monotone(MALTA_HF[k]) || !malta_line_monotone(MALTA_LF[k])) return false;
+    return true;
+}
+static_assert(malta_tables_monotone(), "the row-streaming Malta unit needs every line's rows to be visited in one direction");
 
 // ---- per pair, fused: the three Malta bands of channels X and Y + every channel's L2 terms -----------------------
 // For channel c in {X, Y}: UHF (9-sample lines), HF and MF (5-sample lines).  Per band the two images' 72x72
@@ -626,42 +651,79 @@ __device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_
     return (lo || hi) ? (float)rn : r;
 }
 
-// Channels X and Y are PACKED: the LDS tile holds (x-diff, y-diff) pairs, a thread forms the 16 line sums of MaltaUnit
-// for two horizontally adjacent centres and both channels at once from a 9 x 10 register window of pairs (45 16-byte
-// LDS reads) on v_pk_add_f32 / v_pk_fma_f32 - two IEEE operations each, so every channel's sums are exactly those of a
-// scalar loop, tap order per line as in the lineage - and the block also writes channel B's L2 terms.
-// 72x72 float2 tile + 64x64 float2 running sums = 73 KB: two blocks per CU, 177 VGPRs.  (The scalar form - one channel
-// per block, four centres per thread - took 1.86 ms per four 4K pairs, this one 1.57 ms.)
+// Channels X and Y are PACKED: the LDS tile holds (x-diff, y-diff) pairs and a thread forms the 16 line sums of MaltaUnit
+// for two horizontally adjacent centres and both channels at once on v_pk_add_f32 / v_pk_fma_f32 (two IEEE operations
+// each, so every channel's sums are exactly those of a scalar loop).  The 9 x 10 window of pairs is STREAMED row by
+// row (five 16-byte LDS reads per row) into 32 running line sums instead of being held whole (180 registers, two waves
+// per SIMD, VALU busy 59 %): a line's taps are added in the lineage's order - fourteen of the sixteen lines run top
+// to bottom, so their running sum simply follows the rows; lines 7 and 12 run bottom to top, so their taps are parked
+// until the row of their FIRST tap arrives and are then added in order.  Bit-identical sums, ~150 registers, and with
+// a 64 x 32 tile (72 x 40 pairs + 64 x 32 running sums = 39 KB) three to four blocks per CU.
 template <bool LF>
-__device__ __forceinline__ void malta_unit2_xy(const ba_f2 (&win)[9][10], ba_f2 (&acc)[2])
+__device__ __forceinline__ void malta_rows_xy(const ba_f2 *__restrict__ base, ba_f2 (&acc)[2])
 {
+    ba_f2 sum[2][16];
+    ba_f2 parked[2][16][9];  // only the entries of the two bottom-up lines are ever touched (all indices are static)
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+        ba_f2 v[10];
+        const float4 *row = reinterpret_cast<const float4 *>(base + r * ML);
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const float4 t = row[q];
+            v[2 * q] = ba_f2{t.x, t.y};
+            v[2 * q + 1] = ba_f2{t.z, t.w};
+        }
+        const int dy = r - 4;
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const mline &ln = LF ? MALTA_LF[k] : MALTA_HF[k];
+                if (!malta_line_descends(ln)) {
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        if (j < ln.n && ln.d[j][1] == dy) {
+                            const ba_f2 t = v[4 + o + ln.d[j][0]];
+                            sum[o][k] = j == 0 ? t : sum[o][k] + t;  // 0 + t == t: the lineage's sum starts at zero
+                        }
+                } else if (dy == ln.d[0][1]) {  // the row of the line's first tap: everything below it is parked
+                    ba_f2 acc_k = {0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        if (j < ln.n) {
+                            const ba_f2 t = ln.d[j][1] == dy ? v[4 + o + ln.d[j][0]] : parked[o][k][j];
+                            acc_k = j == 0 ? t : acc_k + t;
+                        }
+                    sum[o][k] = acc_k;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        if (j < ln.n && ln.d[j][1] == dy) parked[o][k][j] = v[4 + o + ln.d[j][0]];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int o = 0; o < 2; o++) {
         ba_f2 ret = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const mline &ln = LF ? MALTA_LF[k] : MALTA_HF[k];
-            ba_f2 sum = {0.0f, 0.0f};
-#pragma unroll
-            for (int j = 0; j < 9; j++)
-                if (j < ln.n) sum = sum + win[4 + ln.d[j][1]][4 + o + ln.d[j][0]];
-            ret = __builtin_elementwise_fma(sum, sum, ret);
-        }
+        for (int k = 0; k < 16; k++) ret = __builtin_elementwise_fma(sum[o][k], sum[o][k], ret);
         acc[o] = acc[o] + ret;
     }
 }
 
-__global__ __launch_bounds__(TPB, 2) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+__global__ __launch_bounds__(TPB, 3) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
                                                            float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
                                                            uint32_t n_pairs_stride, malta_bands mb)
 {
-    __shared__ __attribute__((aligned(16))) ba_f2 s[ML * ML];
-    __shared__ __attribute__((aligned(16))) ba_f2 s_acc[MT * MT];  // the block's running sums; each thread owns its entries
+    __shared__ __attribute__((aligned(16))) ba_f2 s[MLR * ML];
+    __shared__ __attribute__((aligned(16))) ba_f2 s_acc[MR * MT];  // the block's running sums; each thread owns its entries
     const uint32_t p = blockIdx.z;
-    const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MT - MH;
+    const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MR - MH;
     const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane;
     const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane;
-    // thread -> two adjacent outputs (columns 2*tq, 2*tq+1 of row 8*sub + ty), eight row groups per tile
+    // thread -> two adjacent outputs (columns 2*tq, 2*tq+1 of row 8*sub + ty), four row groups per tile
     const int tq = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int band = 0; band < 3; band++) {
@@ -669,7 +731,7 @@ __global__ __launch_bounds__(TPB, 2) void k_ba_malta_l2_xy(const float *__restri
         const uint32_t plane0 = band == 0 ? UHF0 : band == 1 ? HF0 : MF0;  // channel X's plane; channel Y's is the next one
         const float *pax = a + (size_t)plane0 * g.plane, *pbx = b + (size_t)plane0 * g.plane;
         const float *pay = pax + g.plane, *pby = pbx + g.plane;
-        for (int i = threadIdx.x; i < ML * (ML / 4); i += TPB) {
+        for (int i = threadIdx.x; i < MLR * (ML / 4); i += TPB) {
             const int ly = i / (ML / 4), lq = i % (ML / 4), gx = x0 + 4 * lq, gy = y0 + ly;
             float4 vax = make_float4(0.f, 0.f, 0.f, 0.f), vbx = vax, vay = vax, vby = vax;
             const bool in = gx >= 0 && gy >= 0 && gx < (int)g.pitch && gy < (int)g.h;
@@ -696,24 +758,14 @@ __global__ __launch_bounds__(TPB, 2) void k_ba_malta_l2_xy(const float *__restri
         }
         __syncthreads();
 #pragma unroll 1
-        for (int sub = 0; sub < 8; sub++) {
+        for (int sub = 0; sub < MR / 8; sub++) {
             ba_f2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};  // this band's sums; 0 + ret is exact, so adding them afterwards is the same sum
-            ba_f2 win[9][10];
-#pragma unroll
-            for (int r = 0; r < 9; r++) {
-                const float4 *row = reinterpret_cast<const float4 *>(s + (8 * sub + ty + r) * ML + 2 * tq);
-#pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    const float4 v = row[q];
-                    win[r][2 * q] = ba_f2{v.x, v.y};
-                    win[r][2 * q + 1] = ba_f2{v.z, v.w};
-                }
-            }
+            const ba_f2 *base = s + (8 * sub + ty) * ML + 2 * tq;
             // block_diff_ac accumulates band by band in the lineage: same order here
             if (band == 0)
-                malta_unit2_xy<false>(win, acc);
+                malta_rows_xy<false>(base, acc);
             else
-                malta_unit2_xy<true>(win, acc);
+                malta_rows_xy<true>(base, acc);
             float4 *pacc = reinterpret_cast<float4 *>(s_acc + (8 * sub + ty) * MT + 2 * tq);
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (band != 0) t = *pacc;
@@ -724,10 +776,10 @@ __global__ __launch_bounds__(TPB, 2) void k_ba_malta_l2_xy(const float *__restri
     const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
     const float hf_asymmetry = 1.0f;
 #pragma unroll 1
-    for (int sub = 0; sub < 8; sub++)
+    for (int sub = 0; sub < MR / 8; sub++)
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const uint32_t x = blockIdx.x * MT + 2 * tq + r, y = blockIdx.y * MT + 8 * sub + ty;
+        const uint32_t x = blockIdx.x * MT + 2 * tq + r, y = blockIdx.y * MR + 8 * sub + ty;
         if (x >= g.w || y >= g.h) continue;
         const size_t o = (size_t)y * g.pitch + x;
         const ba_f2 sums = s_acc[(8 * sub + ty) * MT + 2 * tq + r];
@@ -773,13 +825,14 @@ __device__ __forceinline__ float mask_pre_one(const float *__restrict__ a, size_
     return sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
 }
 
-__global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
-                                                     float *__restrict__ m0, float *__restrict__ m1, geom g, uint32_t max_refs)
+// per IMAGE SLOT (the mask input depends on one image only, so a reference's is computed once per reference - and kept
+// by a reference handle - instead of once per pair)
+__global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ psy, float *__restrict__ m, geom g, uint32_t n_refs_used,
+                                                     uint32_t max_refs, uint32_t z0)
 {
-    const uint32_t p = blockIdx.z;
+    const uint32_t slot = slot_of(blockIdx.z + z0, n_refs_used, max_refs);
     BA_XY;
-    m0[(size_t)p * g.plane + o] = mask_pre_one(psy + (size_t)pair_ref[p] * PSY * g.plane + o, g.plane);
-    m1[(size_t)p * g.plane + o] = mask_pre_one(psy + (size_t)(max_refs + p) * PSY * g.plane + o, g.plane);
+    m[(size_t)slot * g.plane + o] = mask_pre_one(psy + (size_t)slot * PSY * g.plane + o, g.plane);
 }
 
 // StoreMin3: keep the three smallest values seen, sorted.  The state (min0 <= min1 <= min2) starts sorted for the
@@ -795,13 +848,14 @@ __device__ __forceinline__ void store_min3(float v, float &min0, float &min1, fl
 }
 
 // mask = FuzzyErosion(blurred0); ac[1] += 10 (blurred0 - blurred1)^2; then CombineChannelsToDiffmap — one pass
-__global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict__ bl0, const float *__restrict__ bl1,
+__global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict__ blurred, const uint32_t *__restrict__ pair_ref,
                                                          const float *__restrict__ ac, const float *__restrict__ dc,
-                                                         float *__restrict__ diffmap, geom g, uint32_t n_pairs_stride)
+                                                         float *__restrict__ diffmap, geom g, uint32_t n_pairs_stride, uint32_t max_refs)
 {
     const uint32_t p = blockIdx.z;
     BA_XY;
-    const float *from = bl0 + (size_t)p * g.plane;
+    const float *from = blurred + (size_t)pair_ref[p] * g.plane;  // the reference's blurred mask input (per-slot planes)
+    const float *bl1 = blurred + (size_t)max_refs * g.plane;       // ... the distorted images' follow the references' 
     const int X = (int)x, Y = (int)y, W = (int)g.w, H = (int)g.h, S = 3;
     const uint32_t pitch = g.pitch;
 #define at(yy, xx) from[(size_t)(yy) * pitch + (xx)]
@@ -970,25 +1024,25 @@ float inv_weight_sum(const blur_kernel &bk)
 
 template <int LEN>
 int launch_blur_len(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g, plane_sel si, plane_sel st, plane_sel so,
-                    const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot)
+                    const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot, uint32_t z0)
 {
     const float inv = inv_weight_sum(bk);
     const dim3 gh((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
     static const std::string name_h = "ba_blur_h" + std::to_string(LEN), name_v = "ba_blur_v" + std::to_string(LEN);
-    CE_LAUNCH(ctx, name_h.c_str(), k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot, 0u);
-    CE_LAUNCH(ctx, name_v.c_str(), k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot);
+    CE_LAUNCH(ctx, name_h.c_str(), k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot, z0);
+    CE_LAUNCH(ctx, name_v.c_str(), k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot, z0);
     return CE_OK;
 }
 
 // in[si] -> (row pass) tmp[st] -> (column pass) out[so]
 int launch_blur(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g, plane_sel si, plane_sel st, plane_sel so,
-                const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot)
+                const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot, uint32_t z0)
 {
     switch (bk.len) {
-        case 7: return launch_blur_len<7>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
-        case 13: return launch_blur_len<13>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
-        case 15: return launch_blur_len<15>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
-        case 33: return launch_blur_len<33>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot);
+        case 7: return launch_blur_len<7>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
+        case 13: return launch_blur_len<13>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
+        case 15: return launch_blur_len<15>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
+        case 33: return launch_blur_len<33>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
     }
     ctx->err = "unexpected blur kernel length";
     return CE_ERR_BACKEND;
@@ -1011,7 +1065,8 @@ void ce_butteraugli_free(ce_batch *b)
         hipFree(b->ba_lin[l]);
         hipFree(b->ba_psy[l]);
         hipFree(b->ba_diff[l]);
-        b->ba_lin[l] = b->ba_psy[l] = b->ba_diff[l] = nullptr;
+        hipFree(b->ba_mask[l]);
+        b->ba_lin[l] = b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
     }
     for (auto &p : b->ba_s) hipFree(p), p = nullptr;
     for (auto &p : b->ba_pp) hipFree(p), p = nullptr;
@@ -1044,9 +1099,11 @@ static int ba_allocate(ce_batch *b)
         CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));
     }
     for (auto &p : b->ba_s) CE_HIP(ctx, hipMalloc(&p, slots * 3 * p0 * sizeof(float)));
-    // pair scratch: 0 diffs, 1 ac[3], 2 dc[3], 3 m0, 4 m1, 5 bl0, 6 bl1, 7 tmp, 8 mask
-    const size_t pp_planes[9] = {1, 3, 3, 1, 1, 1, 1, 1, 1};
-    for (int i = 0; i < 9; i++) CE_HIP(ctx, hipMalloc(&b->ba_pp[i], P * pp_planes[i] * p0 * sizeof(float)));
+    // pair scratch: 1 ac[3], 2 dc[3]
+    CE_HIP(ctx, hipMalloc(&b->ba_pp[1], P * 3 * p0 * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->ba_pp[2], P * 3 * p0 * sizeof(float)));
+    // blurred mask input, per image slot and level (persists like the PsychoImage)
+    for (int l = 0; l < b->ba_levels; l++) CE_HIP(ctx, hipMalloc(&b->ba_mask[l], slots * b->ba[l].plane * sizeof(float)));
     b->ba_blocks = ((b->ba[0].w + 63) / 64) * ((b->ba[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ba_blk_max, P * b->ba_blocks * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ba_blk_sums, P * b->ba_blocks * 3 * sizeof(double)));
@@ -1137,19 +1194,19 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         }
 
         // ---- per pair ----
-        float *ac = b->ba_pp[1], *dc = b->ba_pp[2], *m0 = b->ba_pp[3], *m1 = b->ba_pp[4],
-              *bl0 = b->ba_pp[5], *bl1 = b->ba_pp[6], *tmp = b->ba_pp[7];
-        const dim3 mg((d.w + MT - 1) / MT, (d.h + MT - 1) / MT, n_pairs);
+        float *ac = b->ba_pp[1], *dc = b->ba_pp[2];
+        const dim3 mg((d.w + MT - 1) / MT, (d.h + MR - 1) / MR, n_pairs);
         malta_bands mb;
         mb.p[0][0] = mUhfX; mb.p[0][1] = mHfX; mb.p[0][2] = mMfX;
         mb.p[1][0] = mUhfY; mb.p[1][1] = mHfY; mb.p[1][2] = mMfY;
         CE_LAUNCH(ctx, "ba_malta_l2", k_ba_malta_l2_xy, mg, dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P, mb);
-        // mask
+        // mask input: DiffPrecompute of HF + UHF, blurred with sigma 2.7 - per image slot (the references' once per
+        // reference; cached with the PsychoImage for reference handles), into the level's own per-slot planes
         const plane_sel s1{1, 0, 1};
-        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(n_pairs), dim3(TPB), 0, psy, b->d_pair_ref, m0, m1, g, mr);
-        if ((rc = launch_blur(ctx, m0, tmp, bl0, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
-        if ((rc = launch_blur(ctx, m1, tmp, bl1, g, s1, s1, s1, kMask, n_pairs, 0u, 0u, 0)) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "ba_mask_combine", k_ba_mask_combine, G(n_pairs), dim3(TPB), 0, bl0, bl1, ac, dc, b->ba_diff[l], g, P);
+        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(nz), dim3(TPB), 0, psy, b->ba_s[0], g, n_refs_used, mr, z0);
+        if ((rc = launch_blur(ctx, b->ba_s[0], b->ba_s[1], b->ba_mask[l], g, s1, s1, s1, kMask, nz, n_refs_used, mr, 1, z0)) != CE_OK) return rc;
+        CE_LAUNCH(ctx, "ba_mask_combine", k_ba_mask_combine, G(n_pairs), dim3(TPB), 0, (const float *)b->ba_mask[l], b->d_pair_ref, ac, dc,
+                  b->ba_diff[l], g, P, mr);
     }
     if (b->keep_ref_pyramid && !cached) {
         b->ba_ref_src = d_refs;

@@ -213,8 +213,11 @@ int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_r
     // +16 bytes: the PSNR kernel reads whole 16-byte words
     chk(hipMalloc(&b->d_refs, b->img_bytes * max_refs + 16), "hipMalloc refs");
     chk(hipMalloc(&b->d_tests, b->img_bytes * max_pairs + 16), "hipMalloc tests");
-    chk(hipMalloc(&b->d_pair_ref, sizeof(uint32_t) * 2 * max_pairs), "hipMalloc pair_ref");  // [pair_ref | pair_first]
+    // [pair_ref (P) | pair_first (P) | ref_off (R + 1) | ref_idx (P)]
+    chk(hipMalloc(&b->d_pair_ref, sizeof(uint32_t) * (3 * (size_t)max_pairs + max_refs + 1)), "hipMalloc pair_ref");
     b->d_pair_first = b->d_pair_ref ? b->d_pair_ref + max_pairs : nullptr;
+    b->d_ref_off = b->d_pair_ref ? b->d_pair_ref + 2 * (size_t)max_pairs : nullptr;
+    b->d_ref_idx = b->d_pair_ref ? b->d_ref_off + max_refs + 1 : nullptr;
     chk(hipMalloc(&b->d_scores, sizeof(ce_dev_scores) * max_pairs), "hipMalloc scores");
     chk(hipHostMalloc(&b->h_scores, sizeof(ce_dev_scores) * max_pairs, hipHostMallocDefault), "hipHostMalloc scores");
     chk(hipStreamCreateWithFlags(&b->up_stream, hipStreamNonBlocking), "hipStreamCreate upload");
@@ -506,13 +509,21 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     if (b->pair_ref_dirty) {
         // pair_first[p] = the lowest pair index bound to the same reference as p: that pair's row pass also produces
         // the two reference-only blur streams (a, a*a) which every pair of the reference then reads (ssim2.hip)
-        std::vector<uint32_t> table(2 * (size_t)b->max_pairs), first_of(b->max_refs, ~0u);
-        for (uint32_t i = 0; i < b->max_pairs; i++) {
+        // ... and the inverse table, reference -> its pairs in ascending pair order (kernels that walk a reference's
+        // distorted images with the reference's planes held in registers: dssim.hip)
+        const size_t P = b->max_pairs, R = b->max_refs;
+        std::vector<uint32_t> table(3 * P + R + 1), first_of(R, ~0u), count(R + 1, 0);
+        for (uint32_t i = 0; i < P; i++) {
             const uint32_t r = b->h_pair_ref[i];
             if (first_of[r] == ~0u) first_of[r] = i;
             table[i] = r;
-            table[b->max_pairs + i] = first_of[r];
+            table[P + i] = first_of[r];
+            count[r + 1]++;
         }
+        for (size_t r = 0; r < R; r++) count[r + 1] += count[r];
+        for (size_t r = 0; r <= R; r++) table[2 * P + r] = count[r];
+        std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+        for (uint32_t i = 0; i < P; i++) table[2 * P + R + 1 + fill[b->h_pair_ref[i]]++] = i;
         CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, table.data(), sizeof(uint32_t) * table.size(), hipMemcpyHostToDevice, ctx->stream));
         CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable
         b->pair_ref_dirty = false;
@@ -662,8 +673,8 @@ size_t ce_estimate_batch_bytes(uint32_t w, uint32_t h, uint32_t n_refs, uint32_t
         bytes += px * (20.0 * slots + 80.0 * pairs);
     if (metric_mask & CE_METRIC_DSSIM)  // linear ping-pong 6, img / mu / sq 36 per slot; SSIM map 4 per pair
         bytes += px * (42.0 * slots + 4.0 * pairs);
-    if (metric_mask & CE_METRIC_BUTTERAUGLI)  // half-res linear 3, PsychoImage 50, three 3-plane scratch sets 36 per slot; diffmaps 5 + 12 scratch planes per pair
-        bytes += px * (89.0 * slots + 53.0 * pairs);
+    if (metric_mask & CE_METRIC_BUTTERAUGLI)  // half-res linear 3, PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; diffmaps 5 + ac / dc 24 per pair
+        bytes += px * (94.0 * slots + 29.0 * pairs);
     if (metric_mask & CE_METRIC_PSNR) bytes += 8.0 * pairs;
     return (size_t)(bytes * 1.2) + (8u << 20);  // row / pitch padding of the planar buffers, staging ring
 }

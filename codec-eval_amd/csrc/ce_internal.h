@@ -77,7 +77,8 @@ struct ce_batch {
     uint8_t *d_refs_rt = nullptr;  // XYB-roundtripped references (lazily allocated)
     uint8_t *d_tests = nullptr;    // [max_pairs][h][w][3]
     uint32_t *d_pair_ref = nullptr;
-    uint32_t *d_pair_first = nullptr;  // second half of the d_pair_ref allocation
+    uint32_t *d_pair_first = nullptr;  // second part of the d_pair_ref allocation
+    uint32_t *d_ref_off = nullptr, *d_ref_idx = nullptr;  // ... then reference -> its pairs (CSR: [max_refs + 1] offsets, [max_pairs] pair indices)
     std::vector<uint32_t> h_pair_ref;
     bool pair_ref_dirty = true;
     std::tuple<uint32_t, uint32_t, uint32_t> pool_key{0, 0, 0};  // (w, h, ring slot) when owned by a context's scratch pool
@@ -158,6 +159,7 @@ struct ce_batch {
     float *ba_lin[2] = {};    // [slot][3][plane_l]
     float *ba_psy[2] = {};    // [slot][10][plane_l]  PsychoImage
     float *ba_diff[2] = {};   // [pair][plane_l]      diffmaps
+    float *ba_mask[2] = {};   // [slot][plane_l]      blurred mask input (DiffPrecompute of HF + UHF, sigma 2.7)
     float *ba_s[3] = {};      // per-slot scratch, 3 planes each
     float *ba_pp[9] = {};     // per-pair scratch
     float *ba_blk_max = nullptr;
