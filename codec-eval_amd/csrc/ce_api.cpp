@@ -669,14 +669,21 @@ size_t ce_estimate_batch_bytes(uint32_t w, uint32_t h, uint32_t n_refs, uint32_t
 {
     const double px = (double)w * h, slots = (double)n_refs + n_pairs, pairs = n_pairs;
     double bytes = 3.0 * px * slots + 64.0 * pairs;  // u8 slabs, scores
-    if (metric_mask & CE_METRIC_SSIMULACRA2)  // linear pyramid (levels >= 1) 4, XYB pyramid 16 per slot; 15 row-blurred planes x 1.333 per pair
+    double allocations = 8;                          // each device allocation is rounded up; budget 256 KiB of slack apiece
+    if (metric_mask & CE_METRIC_SSIMULACRA2) {  // linear pyramid (levels >= 1) 4, XYB pyramid 16 per slot; 15 row-blurred planes x 1.333 per pair
         bytes += px * (20.0 * slots + 80.0 * pairs);
-    if (metric_mask & CE_METRIC_DSSIM)  // linear ping-pong 6, img / mu / sq 36 per slot; SSIM map 4 per pair
-        bytes += px * (42.0 * slots + 4.0 * pairs);
-    if (metric_mask & CE_METRIC_BUTTERAUGLI)  // half-res linear 3, PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; diffmaps 5 + ac / dc 24 per pair
+        allocations += 24;
+    }
+    if (metric_mask & CE_METRIC_DSSIM) {  // linear ping-pong 6, img / mu / sq 36 per slot, the references' per-level planes 48; SSIM map 4 per pair
+        bytes += px * (42.0 * slots + 48.0 * n_refs + 4.0 * pairs);
+        allocations += 24;
+    }
+    if (metric_mask & CE_METRIC_BUTTERAUGLI) {  // half-res linear 3, PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; diffmaps 5 + ac / dc 24 per pair
         bytes += px * (94.0 * slots + 29.0 * pairs);
+        allocations += 20;
+    }
     if (metric_mask & CE_METRIC_PSNR) bytes += 8.0 * pairs;
-    return (size_t)(bytes * 1.2) + (8u << 20);  // row / pitch padding of the planar buffers, staging ring
+    return (size_t)(bytes * 1.2) + (size_t)(allocations * (256u << 10)) + (8u << 20);  // row / pitch padding of the planar buffers
 }
 
 int ce_ctx_memory_info(ce_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
@@ -787,13 +794,23 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
                 groups[it->second].push_back(i);
             }
         }
-        const size_t n_chunks = std::min<size_t>(ce_ctx::kPoolRing, std::max<size_t>(1, idx.size() / 16));
+        // CE_EVAL_BATCH_CHUNKS (1..3, measurement knob): how many chunks a bucket that fits is cut into so that the upload
+        // of one chunk overlaps the kernels of the one before
+        static const size_t want_chunks = [] {
+            const char *e = std::getenv("CE_EVAL_BATCH_CHUNKS");
+            const int v = e ? std::atoi(e) : 0;
+            return (size_t)(v >= 1 && v <= (int)ce_ctx::kPoolRing ? v : (int)ce_ctx::kPoolRing);
+        }();
+        const size_t n_chunks = std::min<size_t>(want_chunks, std::max<size_t>(1, idx.size() / 16));
         size_t target = (idx.size() + n_chunks - 1) / n_chunks;
         // ... and a chunk must fit the device: cap the pairs per chunk by bytes per pair (every pair budgeted with a
         // reference of its own) against a share of the free memory; a grid larger than that streams through the ring
         // in more chunks.  A reference with more tests than the cap is split (its reference is uploaded once per part).
         {
-            const size_t per_pair = ce_estimate_batch_bytes(kv.first.first, kv.first.second, 1, 1, metric_mask) - (8u << 20);
+            const size_t per_pair = ce_estimate_batch_bytes(kv.first.first, kv.first.second, 1, 2, metric_mask) -
+                                    ce_estimate_batch_bytes(kv.first.first, kv.first.second, 1, 1, metric_mask) +
+                                    ce_estimate_batch_bytes(kv.first.first, kv.first.second, 2, 1, metric_mask) -
+                                    ce_estimate_batch_bytes(kv.first.first, kv.first.second, 1, 1, metric_mask);  // a pair with a reference of its own
             const size_t cap = std::max<size_t>(1, chunk_budget(ctx) / std::max<size_t>(per_pair, 1));
             target = std::min(target, cap);
             std::vector<std::vector<size_t>> split;

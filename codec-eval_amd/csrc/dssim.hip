@@ -253,13 +253,12 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
 // ---- Dssim::compare for one level, fused: i12 = blur(img1*img2) in LDS (tile + halo 2), then compare_scale ----
 constexpr int CR = DT + 4;
 
-// Dssim::compare for one level.  A block owns one 32x32 tile of one REFERENCE and walks the reference's distorted
-// images one after the other: the reference's img tile, its mu and blur(img^2) are then read by the same block at the
-// same addresses for every distorted image, i.e. from L1 / the XCD's L2 after the first, and cross HBM once per
-// reference instead of once per pair (PMC, round 2: 146 B per scale-0 pixel of a pair with one pair per block, against
-// 69 algorithmic).  Per distorted image the arithmetic - and the order of every sum - is what it was: product tile ->
-// two 3x3 passes in LDS -> channel-averaged SSIM -> map + block sum.  (Holding the reference side in registers across
-// the loop instead costs 60 more VGPRs than the kernel has at four waves per SIMD.)
+// (A variant in which a block walks ALL distorted images of one reference, so that the reference's nine planes are read
+// from cache after the first, was measured in round 2: 0.85 ms per step against 0.70 ms for this one-pair-per-block
+// form on the Kodak grid - the per-block loop with two barriers per distorted image costs more latency than the
+// reference re-reads cost bandwidth; with 24 x 16 tiles per image the blocks of consecutive pairs of a reference
+// already land on the same XCD, 384 = 0 mod 8.)
+// the blur of img1*img2 (second pass) and compare_scale on the LDS planes; IN = the block's 36x36 region is inside the image
 template <bool IN>
 __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], float (&T)[3][CR * CR], const float *__restrict__ mu,
                                                        const float *__restrict__ sq, const float *__restrict__ rmu,
@@ -307,36 +306,29 @@ __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], f
 __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ mu,
                                                        const float *__restrict__ sq, const float *__restrict__ rimg,
                                                        const float *__restrict__ rmu, const float *__restrict__ rsq,
-                                                       const uint32_t *__restrict__ ref_off, const uint32_t *__restrict__ ref_idx,
+                                                       const uint32_t *__restrict__ pair_ref,
                                                        float *__restrict__ map, double *__restrict__ part, lvl_geom g,
-                                                       uint32_t max_refs, uint32_t n_pairs, uint32_t level, uint32_t n_levels,
-                                                       uint32_t n_blocks)
+                                                       uint32_t max_refs, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
 {
     __shared__ float M[3][CR * CR], T[3][CR * CR];
     __shared__ double s_red[TPB / 64];
-    const uint32_t r = blockIdx.z;
-    const uint32_t k0 = ref_off[r], k1 = ref_off[r + 1];
+    const uint32_t p = blockIdx.z;
     const int w = (int)g.w, h = (int)g.h;
     const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 2, gy0 = y0 - 2;
-    const size_t sa = (size_t)r * 3 * g.plane;
-    const bool interior = gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h;
-    for (uint32_t k = k0; k < k1; k++) {  // block-uniform trip count
-        const uint32_t p = ref_idx[k];
-        if (p >= n_pairs) continue;  // a pair slot beyond this launch
-        const size_t sb = (size_t)(max_refs + p) * 3 * g.plane;
-        for (int i = threadIdx.x; i < CR * CR; i += TPB) {
-            const int lx = i % CR, ly = i / CR;
-            const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
-            const size_t o = (size_t)Y * g.pitch + X;
+    const size_t sa = (size_t)pair_ref[p] * 3 * g.plane, sb = (size_t)(max_refs + p) * 3 * g.plane;
+    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
+        const int lx = i % CR, ly = i / CR;
+        const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
+        const size_t o = (size_t)Y * g.pitch + X;
 #pragma unroll
-            for (int c = 0; c < 3; c++) M[c][i] = rimg[sa + c * g.plane + o] * img[sb + c * g.plane + o];
-        }
-        __syncthreads();
-        const double val = interior ? dssim_compare_stages<true>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0)
-                                    : dssim_compare_stages<false>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0);
-        const double t = block_sum(val, s_red);  // ends with a barrier: M and T are free for the next distorted image
-        if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
+        for (int c = 0; c < 3; c++) M[c][i] = rimg[sa + c * g.plane + o] * img[sb + c * g.plane + o];
     }
+    __syncthreads();
+    const double val = (gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h)
+                           ? dssim_compare_stages<true>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0)
+                           : dssim_compare_stages<false>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0);
+    const double t = block_sum(val, s_red);
+    if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
 
 // ---- avg = max(mean, 0)^(0.5^level): one block per pair reduces the SSIM partial sums in a fixed order ----
@@ -518,9 +510,9 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                       ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img, b->ds_mu, b->ds_sq,
                       b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         // compare per pair
-        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(tiles.x, tiles.y, n_refs_used), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
-                  (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], (const uint32_t *)b->d_ref_off,
-                  (const uint32_t *)b->d_ref_idx, b->ds_map, b->ds_part, lg, mr, n_pairs, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
+        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(tiles.x, tiles.y, n_pairs), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
+                  (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
+                  b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
                   (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
         const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);
