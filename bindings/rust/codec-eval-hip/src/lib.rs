@@ -188,6 +188,29 @@ impl<'a> HipSsim2Reference<'a> {
     }
 }
 
+impl HipSsim2Reference<'_> {
+    /// All metrics against the resident reference (the handle keeps every metric's reference-side state: XYB roundtrip,
+    /// SSIMULACRA2 XYB pyramid, DSSIM img / mu / blur(img^2) pyramid, Butteraugli PsychoImage).  `scores[i].status`
+    /// reports per-item failures.
+    pub fn compare_many_metrics(&mut self, distorted: &[&[u8]], mask: u32, intensity_target: f32) -> Result<Vec<sys::ce_scores>, HipError> {
+        let ptrs: Vec<*const u8> = distorted.iter().map(|d| d.as_ptr()).collect();
+        let lens: Vec<usize> = distorted.iter().map(|d| d.len()).collect();
+        let mut out = vec![sys::ce_scores::default(); distorted.len()];
+        let rc = unsafe {
+            sys::ce_ref_compare_many(self.handle, ptrs.as_ptr(), lens.as_ptr(), distorted.len() as u32, mask, intensity_target, out.as_mut_ptr())
+        };
+        self.owner.check(rc, self.width, self.height, 0)?;
+        Ok(out)
+    }
+
+    /// Compares so far that had to (re)build the reference side of (SSIMULACRA2, DSSIM, Butteraugli).
+    pub fn reference_builds(&self) -> [u32; 3] {
+        let mut b = [0u32; 3];
+        unsafe { sys::ce_ref_stats(self.handle, b.as_mut_ptr()) };
+        b
+    }
+}
+
 impl Drop for HipSsim2Reference<'_> {
     fn drop(&mut self) {
         unsafe { sys::ce_ref_destroy(self.handle) }

@@ -794,14 +794,18 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
                 groups[it->second].push_back(i);
             }
         }
-        // CE_EVAL_BATCH_CHUNKS (1..3, measurement knob): how many chunks a bucket that fits is cut into so that the upload
-        // of one chunk overlaps the kernels of the one before
-        static const size_t want_chunks = [] {
+        // How many chunks a bucket that fits is cut into (the upload of one chunk then overlaps the kernels of the one
+        // before).  Measured on the 54-pair Kodak bucket with three metrics (round 2): one chunk 9.1 ms per grid, two 12.7,
+        // three 10.1 - small launches cost more than the hidden upload saves - so a bucket is only cut once it holds at
+        // least 64 pairs per chunk; buckets of different shapes still overlap (each has its own batch and upload stream).
+        // CE_EVAL_BATCH_CHUNKS (1..3) forces the count for A/B runs.
+        static const size_t forced_chunks = [] {
             const char *e = std::getenv("CE_EVAL_BATCH_CHUNKS");
             const int v = e ? std::atoi(e) : 0;
-            return (size_t)(v >= 1 && v <= (int)ce_ctx::kPoolRing ? v : (int)ce_ctx::kPoolRing);
+            return (size_t)(v >= 1 && v <= (int)ce_ctx::kPoolRing ? v : 0);
         }();
-        const size_t n_chunks = std::min<size_t>(want_chunks, std::max<size_t>(1, idx.size() / 16));
+        const size_t n_chunks = forced_chunks ? std::min<size_t>(forced_chunks, std::max<size_t>(1, idx.size()))
+                                              : std::min<size_t>(ce_ctx::kPoolRing, std::max<size_t>(1, idx.size() / 64));
         size_t target = (idx.size() + n_chunks - 1) / n_chunks;
         // ... and a chunk must fit the device: cap the pairs per chunk by bytes per pair (every pair budgeted with a
         // reference of its own) against a share of the free memory; a grid larger than that streams through the ring

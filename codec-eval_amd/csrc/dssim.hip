@@ -259,11 +259,14 @@ constexpr int CR = DT + 4;
 // reference re-reads cost bandwidth; with 24 x 16 tiles per image the blocks of consecutive pairs of a reference
 // already land on the same XCD, 384 = 0 mod 8.)
 // the blur of img1*img2 (second pass) and compare_scale on the LDS planes; IN = the block's 36x36 region is inside the image
+constexpr int CMP_OUT = DT * DT / TPB;  // output pixels per thread (4)
+struct cmp_stats {
+    float u1[CMP_OUT][3], u2[CMP_OUT][3], q1[CMP_OUT][3], q2[CMP_OUT][3];  // mu and blur(img^2) of both images at this thread's pixels
+};
+
 template <bool IN>
-__device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], float (&T)[3][CR * CR], const float *__restrict__ mu,
-                                                       const float *__restrict__ sq, const float *__restrict__ rmu,
-                                                       const float *__restrict__ rsq, float *__restrict__ map, const lvl_geom &g,
-                                                       size_t sa, size_t sb, uint32_t p, int x0, int y0)
+__device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], float (&T)[3][CR * CR], const cmp_stats &st,
+                                                       float *__restrict__ map, const lvl_geom &g, uint32_t p, int x0, int y0)
 {
     const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 2, gy0 = y0 - 2;
     for (int i = threadIdx.x; i < CR * CR; i += TPB) {
@@ -275,7 +278,9 @@ __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], f
     }
     __syncthreads();
     double val = 0.0;
-    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+#pragma unroll
+    for (int k = 0; k < CMP_OUT; k++) {
+        const int i = k * TPB + (int)threadIdx.x;
         const int tx = i % DT, ty = i / DT, lx = tx + 2, ly = ty + 2, X = x0 + tx, Y = y0 + ty;
         if (IN || (X < w && Y < h)) {
             const size_t o = (size_t)Y * g.pitch + X;
@@ -283,12 +288,12 @@ __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], f
             float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float u1 = rmu[sa + c * g.plane + o], u2 = mu[sb + c * g.plane + o];
+                const float u1 = st.u1[k][c], u2 = st.u2[k][c];
                 m11[c] = u1 * u1;
                 m12[c] = u1 * u2;
                 m22[c] = u2 * u2;
-                s1[c] = rsq[sa + c * g.plane + o] - m11[c];
-                s2[c] = sq[sb + c * g.plane + o] - m22[c];
+                s1[c] = st.q1[k][c] - m11[c];
+                s2[c] = st.q2[k][c] - m22[c];
                 s12[c] = pass3x3<CR, false, IN>(T[c], lx, ly, gx0, gy0, w, h) - m12[c];
             }
 #define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
@@ -316,6 +321,23 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
     const int w = (int)g.w, h = (int)g.h;
     const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 2, gy0 = y0 - 2;
     const size_t sa = (size_t)pair_ref[p] * 3 * g.plane, sb = (size_t)(max_refs + p) * 3 * g.plane;
+    // The kernel waits on memory, not on arithmetic (round-2 counters: VALU busy 0.34, 0.65 of the wave-cycles parked),
+    // in TWO rounds - the product tile, then mu / blur(img^2) behind two barriers.  The second round is requested here,
+    // before the first, so both are in flight together (48 registers; pixels outside the image are clamped, never used).
+    cmp_stats st;
+#pragma unroll
+    for (int k = 0; k < CMP_OUT; k++) {
+        const int i = k * TPB + (int)threadIdx.x;
+        const int X = min(x0 + i % DT, w - 1), Y = min(y0 + i / DT, h - 1);
+        const size_t o = (size_t)Y * g.pitch + X;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            st.u1[k][c] = rmu[sa + c * g.plane + o];
+            st.u2[k][c] = mu[sb + c * g.plane + o];
+            st.q1[k][c] = rsq[sa + c * g.plane + o];
+            st.q2[k][c] = sq[sb + c * g.plane + o];
+        }
+    }
     for (int i = threadIdx.x; i < CR * CR; i += TPB) {
         const int lx = i % CR, ly = i / CR;
         const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
@@ -325,8 +347,8 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
     }
     __syncthreads();
     const double val = (gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h)
-                           ? dssim_compare_stages<true>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0)
-                           : dssim_compare_stages<false>(M, T, mu, sq, rmu, rsq, map, g, sa, sb, p, x0, y0);
+                           ? dssim_compare_stages<true>(M, T, st, map, g, p, x0, y0)
+                           : dssim_compare_stages<false>(M, T, st, map, g, p, x0, y0);
     const double t = block_sum(val, s_red);
     if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
 }
