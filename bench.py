@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="timed region with every launch on one stream, one kernel at a time (for rocprofv3 traces whose per-kernel "
                          "durations are the kernels' own, not their share of an overlapped schedule)")
+    ap.add_argument("--one-shape", action="store_true",
+                    help="experiment: all 24 references of a Kodak set in the 768x512 shape (one bucket, same pixel count) - the upper "
+                         "bound of what a merged two-bucket launch could gain")
     ap.add_argument("--depth", type=int, default=0, help="batches in flight per shape bucket (default 2: step k+1 is launched before step k's scores are collected)")
     return ap.parse_args()
 
@@ -123,13 +126,14 @@ def main():
     partition_mode = "reference"
     launches_cfg = []  # [(grid, MetricConfig)] of this rank: one resident batch each
     if cfg_id in (0, 2):
-        shapes_all = wl.kodak_corpus_shapes(world)
+        shapes_all = wl.kodak_corpus_shapes(world) if not args.one_shape else [(768, 512)] * (24 * world)
         ids = [g for g in range(24 * world) if not args.quick or g % 24 in (0, 1, 2, 3, 4, 18)]  # --quick: 5 + 1 per set
         shapes = [shapes_all[g] for g in ids]
         pix = [w * h for (w, h) in shapes]
         mode, units, loads = sh.plan_partition(pix, [len(qualities)] * len(pix), 1, world)
         mine = sorted({ids[i] for i, _ in units[rank]})
-        grids = wl.kodak_corpus_shard(mine, qualities, seed0=1000)
+        grids = (wl.kodak_corpus_shard(mine, qualities, seed0=1000) if not args.one_shape else
+                 [wl._grid("kodak-768x512", 768, 512, 0, 1000, qualities, only=mine)])
         cfg = ce.MetricConfig.perceptual() if cfg_id == 0 else ce.MetricConfig.ssimulacra2_only()
         launches_cfg = [(g, cfg) for g in grids]
         n_global_refs = len(ids)

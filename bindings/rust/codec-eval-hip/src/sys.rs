@@ -121,5 +121,6 @@ extern "C" {
     pub fn ce_debug_ssim2_averages(b: *mut ce_batch, pair_index: u32, avg: *mut c_double, n_scales: *mut c_int) -> c_int;
     pub fn ce_debug_ssim2_occupancy(which: c_int) -> c_int;
     pub fn ce_debug_cbrt_sweep(ctx: *mut ce_ctx, first_bits: u32, count: u64, mismatches: *mut u64, slow_path: *mut u64) -> c_int;
+    pub fn ce_debug_div_sweep(ctx: *mut ce_ctx, seed: u64, count: u64, mismatches: *mut u64) -> c_int;
     pub fn ce_debug_calibrate_traffic(ctx: *mut ce_ctx, bytes: usize) -> c_int;
 }

@@ -152,6 +152,7 @@ _PROTOTYPES = [
     ("ce_debug_ssim2_averages", _i, [_vp, _u32, _dp, C.POINTER(_i)]),
     ("ce_debug_ssim2_occupancy", _i, [_i]),
     ("ce_debug_cbrt_sweep", _i, [_vp, _u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("ce_debug_div_sweep", _i, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("ce_debug_calibrate_traffic", _i, [_vp, _sz]),
 ]
 ABI_SYMBOLS = [p[0] for p in _PROTOTYPES]
@@ -335,6 +336,12 @@ class Context:
         free, total = C.c_size_t(), C.c_size_t()
         self._check(lib().ce_ctx_memory_info(self._h, C.byref(free), C.byref(total)))
         return free.value, total.value
+
+    def debug_div_sweep(self, seed: int, count: int) -> int:
+        """Mismatches between the shared-reciprocal division of the Malta pre-scaling and operator/ (must be 0)."""
+        bad = C.c_uint64()
+        self._check(lib().ce_debug_div_sweep(self._h, seed, count, C.byref(bad)))
+        return bad.value
 
     def debug_calibrate_traffic(self, nbytes: int):
         """Run the known-byte-count calibration streams (profiles/make_traffic.py reads them from a PMC pass)."""

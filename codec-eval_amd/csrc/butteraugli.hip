@@ -17,6 +17,7 @@
 // (k_ba_blur_h / k_ba_blur_v).  Build with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include "ce_internal.h"
@@ -592,7 +593,7 @@ __device__ constexpr mline MALTA_LF[16] = {
 };
 
 // 64 x 32 outputs per block from a zero-padded 72 x 40 LDS tile of (x, y) pairs (1.41x halo)
-constexpr int MT = 64, MR = 32, MH = 4, ML = MT + 2 * MH, MLR = MR + 2 * MH;
+constexpr int MT = 64, MH = 4, ML = MT + 2 * MH;
 
 // a Malta line whose taps run from the bottom row to the top one (every other line runs top to bottom)
 __device__ constexpr bool malta_line_descends(const mline &ln)
@@ -628,13 +629,33 @@ struct malta_bands {
     malta_params p[2][3];  // [channel][band: uhf, hf, mf]
 };
 
+// Two correctly rounded f32 quotients a0 / b and a1 / b with ONE reciprocal.  hipcc expands every IEEE division into
+// v_div_scale x2, v_rcp, two fused steps that refine the reciprocal, a product, two fused quotient corrections, v_div_fmas
+// and v_div_fixup (11 instructions) and does not share anything between two divisions by the same denominator.  For
+// operands whose quotient cannot overflow, underflow or involve a denormal - here b = norm1 + |..| in [5, 2^28] and
+// the numerators are positive constants in [2, 4e7] - v_div_scale returns its operand unchanged, v_div_fmas is a plain
+// fma and v_div_fixup returns the quotient, so the same arithmetic is 3 shared + 5 per numerator = 13 instructions
+// instead of 22, bit for bit (ce_debug_div_sweep checks it against operator/ on the device).
+__device__ __forceinline__ void div2_shared_rcp(float a0, float a1, float b, float &q0, float &q1)
+{
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    const float r = __builtin_fmaf(e, r0, r0);
+    float q = a0 * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a0), r, q);
+    q0 = __builtin_fmaf(__builtin_fmaf(-b, q, a0), r, q);
+    q = a1 * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a1), r, q);
+    q1 = __builtin_fmaf(__builtin_fmaf(-b, q, a1), r, q);
+}
+
 __device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_params &mp)
 {
     const float absval = 0.5f * (fabsf(v0) + fabsf(v1));
     const float diff = v0 - v1;
-    const float scaler = mp.norm2_0gt1 / (mp.norm1 + absval);
+    float scaler, scaler2;  // norm2_0gt1 / (norm1 + absval), norm2_0lt1 / (norm1 + absval)
+    div2_shared_rcp(mp.norm2_0gt1, mp.norm2_0lt1, mp.norm1 + absval, scaler, scaler2);
     float r = scaler * diff;
-    const float scaler2 = mp.norm2_0lt1 / (mp.norm1 + absval);
     const double fabs0 = fabs((double)v0);
     const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
     // The four branches of MaltaDiffMap's asymmetry term, without divergence.  Mirror v1 for a negative v0:
@@ -713,10 +734,15 @@ __device__ __forceinline__ void malta_rows_xy(const ba_f2 *__restrict__ base, ba
     }
 }
 
-__global__ __launch_bounds__(TPB, 3) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
+// MR rows of outputs per block, NT threads (32 threads per output row pair-column, NT / 32 rows per step):
+//   <32, 256>: 72 x 40 tile (1.41x halo), 39 KB LDS, four blocks per CU
+//   <64, 512>: 72 x 72 tile (1.27x halo: 10 % fewer pre-scalings), 73 KB LDS, two blocks of eight waves per CU
+template <int MR, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
                                                            float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
                                                            uint32_t n_pairs_stride, malta_bands mb)
 {
+    constexpr int MLR = MR + 2 * MH, RSTEP = NT / 32;  // tile rows; output rows per step of the whole block
     __shared__ __attribute__((aligned(16))) ba_f2 s[MLR * ML];
     __shared__ __attribute__((aligned(16))) ba_f2 s_acc[MR * MT];  // the block's running sums; each thread owns its entries
     const uint32_t p = blockIdx.z;
@@ -731,7 +757,7 @@ __global__ __launch_bounds__(TPB, 3) void k_ba_malta_l2_xy(const float *__restri
         const uint32_t plane0 = band == 0 ? UHF0 : band == 1 ? HF0 : MF0;  // channel X's plane; channel Y's is the next one
         const float *pax = a + (size_t)plane0 * g.plane, *pbx = b + (size_t)plane0 * g.plane;
         const float *pay = pax + g.plane, *pby = pbx + g.plane;
-        for (int i = threadIdx.x; i < MLR * (ML / 4); i += TPB) {
+        for (int i = threadIdx.x; i < MLR * (ML / 4); i += NT) {
             const int ly = i / (ML / 4), lq = i % (ML / 4), gx = x0 + 4 * lq, gy = y0 + ly;
             float4 vax = make_float4(0.f, 0.f, 0.f, 0.f), vbx = vax, vay = vax, vby = vax;
             const bool in = gx >= 0 && gy >= 0 && gx < (int)g.pitch && gy < (int)g.h;
@@ -758,15 +784,15 @@ __global__ __launch_bounds__(TPB, 3) void k_ba_malta_l2_xy(const float *__restri
         }
         __syncthreads();
 #pragma unroll 1
-        for (int sub = 0; sub < MR / 8; sub++) {
+        for (int sub = 0; sub < MR / RSTEP; sub++) {
             ba_f2 acc[2] = {{0.f, 0.f}, {0.f, 0.f}};  // this band's sums; 0 + ret is exact, so adding them afterwards is the same sum
-            const ba_f2 *base = s + (8 * sub + ty) * ML + 2 * tq;
+            const ba_f2 *base = s + (RSTEP * sub + ty) * ML + 2 * tq;
             // block_diff_ac accumulates band by band in the lineage: same order here
             if (band == 0)
                 malta_rows_xy<false>(base, acc);
             else
                 malta_rows_xy<true>(base, acc);
-            float4 *pacc = reinterpret_cast<float4 *>(s_acc + (8 * sub + ty) * MT + 2 * tq);
+            float4 *pacc = reinterpret_cast<float4 *>(s_acc + (RSTEP * sub + ty) * MT + 2 * tq);
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (band != 0) t = *pacc;
             *pacc = make_float4(t.x + acc[0].x, t.y + acc[0].y, t.z + acc[1].x, t.w + acc[1].y);
@@ -776,13 +802,13 @@ __global__ __launch_bounds__(TPB, 3) void k_ba_malta_l2_xy(const float *__restri
     const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
     const float hf_asymmetry = 1.0f;
 #pragma unroll 1
-    for (int sub = 0; sub < MR / 8; sub++)
+    for (int sub = 0; sub < MR / RSTEP; sub++)
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const uint32_t x = blockIdx.x * MT + 2 * tq + r, y = blockIdx.y * MR + 8 * sub + ty;
+        const uint32_t x = blockIdx.x * MT + 2 * tq + r, y = blockIdx.y * MR + RSTEP * sub + ty;
         if (x >= g.w || y >= g.h) continue;
         const size_t o = (size_t)y * g.pitch + x;
-        const ba_f2 sums = s_acc[(8 * sub + ty) * MT + 2 * tq + r];
+        const ba_f2 sums = s_acc[(RSTEP * sub + ty) * MT + 2 * tq + r];
 #pragma unroll
         for (uint32_t c = 0; c < 3; c++) {
             float total = c == 0 ? sums.x : c == 1 ? sums.y : 0.0f;
@@ -996,6 +1022,26 @@ __global__ __launch_bounds__(TPB) void k_ba_score(const float *__restrict__ blk_
     }
 }
 
+// debug: div2_shared_rcp against operator/ on pseudo-random operands of the ranges Malta uses (and wider)
+__global__ __launch_bounds__(256) void k_div_sweep(uint64_t seed, uint64_t count, unsigned long long *out)
+{
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (i + seed) * 0x9E3779B97F4A7C15ull;  // splitmix64
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        // b in [2^0, 2^31), a0 / a1 in [2^-8, 2^31): random mantissas, exponents from the hash
+        const uint32_t mb = (uint32_t)x & 0x7fffffu, ma = (uint32_t)(x >> 23) & 0x7fffffu, m2 = (uint32_t)(x >> 41) & 0x7fffffu;
+        const uint32_t eb = 127u + (uint32_t)((x >> 17) % 31u), ea = 119u + (uint32_t)((x >> 7) % 39u), e2 = 119u + (uint32_t)((x >> 3) % 39u);
+        const float b = __uint_as_float((eb << 23) | mb), a0 = __uint_as_float((ea << 23) | ma), a1 = __uint_as_float((e2 << 23) | m2);
+        float q0, q1;
+        div2_shared_rcp(a0, a1, b, q0, q1);
+        bad += (__float_as_uint(q0) != __float_as_uint(a0 / b)) + (__float_as_uint(q1) != __float_as_uint(a1 / b));
+    }
+    if (bad) atomicAdd(out, bad);
+}
+
 blur_kernel make_kernel(float sigma)
 {
     blur_kernel bk{};
@@ -1058,6 +1104,19 @@ malta_params make_malta(double w_0gt1, double w_0lt1, double norm1, bool lf)
 }
 
 }  // namespace
+
+int ce_butteraugli_div_sweep(ce_ctx *ctx, uint64_t seed, uint64_t count, uint64_t *mismatches)
+{
+    unsigned long long *d = nullptr, h = 0;
+    CE_HIP(ctx, hipMalloc(&d, sizeof(h)));
+    CE_HIP(ctx, hipMemsetAsync(d, 0, sizeof(h), ctx->stream));
+    CE_LAUNCH(ctx, "div_sweep", k_div_sweep, dim3(4096), dim3(256), 0, seed, count, d);
+    CE_HIP(ctx, hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CE_HIP(ctx, hipFree(d));
+    if (mismatches) *mismatches = h;
+    return CE_OK;
+}
 
 void ce_butteraugli_free(ce_batch *b)
 {
@@ -1195,11 +1254,23 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
 
         // ---- per pair ----
         float *ac = b->ba_pp[1], *dc = b->ba_pp[2];
-        const dim3 mg((d.w + MT - 1) / MT, (d.h + MR - 1) / MR, n_pairs);
+        // tile height: 64 rows / 512 threads for images that fill the chip with such tiles, else 32 rows / 256 threads
+        // (CE_MALTA_ROWS=32|64 forces one: measurement knob)
+        static const int forced_rows = [] {
+            const char *e = std::getenv("CE_MALTA_ROWS");
+            const int v = e ? std::atoi(e) : 0;
+            return v == 32 || v == 64 ? v : 0;
+        }();
+        const int malta_rows = forced_rows ? forced_rows : 32;
         malta_bands mb;
         mb.p[0][0] = mUhfX; mb.p[0][1] = mHfX; mb.p[0][2] = mMfX;
         mb.p[1][0] = mUhfY; mb.p[1][1] = mHfY; mb.p[1][2] = mMfY;
-        CE_LAUNCH(ctx, "ba_malta_l2", k_ba_malta_l2_xy, mg, dim3(TPB), 0, psy, b->d_pair_ref, ac, dc, g, mr, P, mb);
+        if (malta_rows == 64)
+            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<64, 512>), dim3((d.w + MT - 1) / MT, (d.h + 63) / 64, n_pairs), dim3(512), 0, psy,
+                      b->d_pair_ref, ac, dc, g, mr, P, mb);
+        else
+            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<32, 256>), dim3((d.w + MT - 1) / MT, (d.h + 31) / 32, n_pairs), dim3(256), 0, psy,
+                      b->d_pair_ref, ac, dc, g, mr, P, mb);
         // mask input: DiffPrecompute of HF + UHF, blurred with sigma 2.7 - per image slot (the references' once per
         // reference; cached with the PsychoImage for reference handles), into the level's own per-slot planes
         const plane_sel s1{1, 0, 1};

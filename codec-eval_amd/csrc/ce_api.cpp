@@ -1203,6 +1203,13 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg, int *
 
 int ce_debug_ssim2_occupancy(int which) { return ce_ssim2_occupancy(which); }
 
+int ce_debug_div_sweep(ce_ctx *ctx, uint64_t seed, uint64_t count, uint64_t *mismatches)
+{
+    if (!ctx || count == 0) return CE_ERR_INVALID_ARG;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    return ce_butteraugli_div_sweep(ctx, seed, count, mismatches);
+}
+
 int ce_debug_calibrate_traffic(ce_ctx *ctx, size_t bytes)
 {
     if (!ctx) return CE_ERR_INVALID_ARG;

@@ -211,6 +211,7 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
 void ce_dssim_free(ce_batch *b);
 int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs, float intensity_target);
 void ce_butteraugli_free(ce_batch *b);
+int ce_butteraugli_div_sweep(ce_ctx *ctx, uint64_t seed, uint64_t count, uint64_t *mismatches);
 int ce_calibrate_traffic(ce_ctx *ctx, size_t bytes);
 int ce_launch_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *d_rgb, float *d_rgba, size_t n_pixels);
 

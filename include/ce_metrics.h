@@ -239,6 +239,10 @@ int ce_debug_ssim2_averages(ce_batch *b, uint32_t pair_index, double *avg /* [6]
 /* resident workgroups per CU that the HIP runtime reports for the SSIMULACRA2 row pass (0) / column pass (1) */
 int ce_debug_ssim2_occupancy(int which);
 int ce_debug_cbrt_sweep(ce_ctx *ctx, uint32_t first_bits, uint64_t count, uint64_t *mismatches, uint64_t *slow_path);
+/* Butteraugli's Malta pre-scaling forms two quotients by one denominator with a hand-expanded division that refines the
+ * reciprocal once (butteraugli.hip: div2_shared_rcp).  This runs `count` pseudo-random operand triples through it and
+ * through operator/ on the device and reports how many quotients differ (must be 0). */
+int ce_debug_div_sweep(ce_ctx *ctx, uint64_t seed, uint64_t count, uint64_t *mismatches);
 /* Known-byte-count streams for calibrating the rocprofv3 traffic counters: reads `bytes` of a scratch buffer with 1, 4
  * and 16 bytes per lane and writes it with 4 and 16 (kernels k_calib_read<W> / k_calib_write<W>), so a PMC pass can
  * measure FETCH_SIZE's / WRITE_SIZE's correction factor per access width (profiles/make_traffic.py). */
