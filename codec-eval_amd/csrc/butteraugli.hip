@@ -740,13 +740,17 @@ __device__ __forceinline__ void malta_rows_xy(const ba_f2 *__restrict__ base, ba
 template <int MR, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
                                                            float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
-                                                           uint32_t n_pairs_stride, malta_bands mb)
+                                                           uint32_t n_pairs_stride, malta_bands mb, const uint2 *__restrict__ work,
+                                                           uint32_t tiles_x)
 {
     constexpr int MLR = MR + 2 * MH, RSTEP = NT / 32;  // tile rows; output rows per step of the whole block
     __shared__ __attribute__((aligned(16))) ba_f2 s[MLR * ML];
     __shared__ __attribute__((aligned(16))) ba_f2 s_acc[MR * MT];  // the block's running sums; each thread owns its entries
-    const uint32_t p = blockIdx.z;
-    const int x0 = blockIdx.x * MT - MH, y0 = blockIdx.y * MR - MH;
+    // XCD-aware 1-D launch (ce_build_xcd_list): the work list says which (tile, pair) this workgroup is
+    const uint2 wi = work[blockIdx.x];
+    if (wi.x == ~0u) return;  // padding entry
+    const uint32_t p = wi.y, bx = wi.x % tiles_x, by = wi.x / tiles_x;
+    const int x0 = (int)bx * MT - MH, y0 = (int)by * MR - MH;
     const float *a = psy + (size_t)pair_ref[p] * PSY * g.plane;
     const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane;
     // thread -> two adjacent outputs (columns 2*tq, 2*tq+1 of row 8*sub + ty), four row groups per tile
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
     for (int sub = 0; sub < MR / RSTEP; sub++)
 #pragma unroll
     for (int r = 0; r < 2; r++) {
-        const uint32_t x = blockIdx.x * MT + 2 * tq + r, y = blockIdx.y * MR + RSTEP * sub + ty;
+        const uint32_t x = bx * MT + 2 * tq + r, y = by * MR + RSTEP * sub + ty;
         if (x >= g.w || y >= g.h) continue;
         const size_t o = (size_t)y * g.pitch + x;
         const ba_f2 sums = s_acc[(RSTEP * sub + ty) * MT + 2 * tq + r];
@@ -1125,6 +1129,7 @@ void ce_butteraugli_free(ce_batch *b)
         hipFree(b->ba_psy[l]);
         hipFree(b->ba_diff[l]);
         hipFree(b->ba_mask[l]);
+        ce_free_xcd_list(&b->ba_work[l]);
         b->ba_lin[l] = b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
     }
     for (auto &p : b->ba_s) hipFree(p), p = nullptr;
@@ -1265,12 +1270,14 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         malta_bands mb;
         mb.p[0][0] = mUhfX; mb.p[0][1] = mHfX; mb.p[0][2] = mMfX;
         mb.p[1][0] = mUhfY; mb.p[1][1] = mHfY; mb.p[1][2] = mMfY;
+        const uint32_t tiles_x = (d.w + MT - 1) / MT, tiles_y = (d.h + (uint32_t)malta_rows - 1) / (uint32_t)malta_rows;
+        if ((rc = ce_build_xcd_list(b, n_pairs, tiles_x * tiles_y, &b->ba_work[l])) != CE_OK) return rc;
         if (malta_rows == 64)
-            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<64, 512>), dim3((d.w + MT - 1) / MT, (d.h + 63) / 64, n_pairs), dim3(512), 0, psy,
-                      b->d_pair_ref, ac, dc, g, mr, P, mb);
+            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<64, 512>), dim3(b->ba_work[l].len), dim3(512), 0, psy, b->d_pair_ref, ac, dc, g, mr, P,
+                      mb, (const uint2 *)b->ba_work[l].d, tiles_x);
         else
-            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<32, 256>), dim3((d.w + MT - 1) / MT, (d.h + 31) / 32, n_pairs), dim3(256), 0, psy,
-                      b->d_pair_ref, ac, dc, g, mr, P, mb);
+            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<32, 256>), dim3(b->ba_work[l].len), dim3(256), 0, psy, b->d_pair_ref, ac, dc, g, mr, P,
+                      mb, (const uint2 *)b->ba_work[l].d, tiles_x);
         // mask input: DiffPrecompute of HF + UHF, blurred with sigma 2.7 - per image slot (the references' once per
         // reference; cached with the PsychoImage for reference handles), into the level's own per-slot planes
         const plane_sel s1{1, 0, 1};

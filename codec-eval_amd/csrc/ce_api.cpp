@@ -94,6 +94,63 @@ static void prof_drain(ce_ctx *ctx)
     ctx->pend.clear();
 }
 
+// XCD-aware launch order for kernels whose workgroup = (tile, pair).  Workgroups reach the 8 XCDs round-robin by launch
+// id and every XCD has its own L2, so the workgroups that read the same tile of one REFERENCE for its different
+// distorted images should carry ids that are congruent mod 8 and adjacent: the reference's planes are then fetched into
+// one XCD's L2 once and hit there by the reference's other pairs (the scheme of the SSIMULACRA2 passes, ssim2.hip).
+// Keys (reference, tile) are dealt to the 8 classes in turn, each key followed by all pairs of its reference;
+// entry id = slot * 8 + class; classes are padded with (~0, 0) entries (the kernel returns at once).  Rebuilt only when
+// the pair -> reference table, the pair count or the tile count changes.
+int ce_build_xcd_list(ce_batch *b, uint32_t n_pairs, uint32_t n_tiles, ce_xcd_list *L)
+{
+    if (L->d && L->version == b->pair_ref_version && L->pairs == n_pairs && L->tiles == n_tiles) return CE_OK;
+    ce_ctx *ctx = b->ctx;
+    std::vector<std::vector<uint32_t>> pairs_of(b->max_refs);
+    for (uint32_t p = 0; p < n_pairs; p++) pairs_of[b->h_pair_ref[p]].push_back(p);
+    static const bool natural = [] {  // CE_XCD_ORDER=0: pair-major, tile-minor (what a 3-D grid would do) - A/B knob
+        const char *e = std::getenv("CE_XCD_ORDER");
+        return e && std::atoi(e) == 0;
+    }();
+    std::vector<uint2> flat;
+    if (natural) {
+        for (uint32_t p = 0; p < n_pairs; p++)
+            for (uint32_t t = 0; t < n_tiles; t++) flat.push_back(make_uint2(t, p));
+    } else {
+        std::vector<uint2> cls[8];
+        uint32_t k = 0;
+        for (uint32_t r = 0; r < b->max_refs; r++) {
+            if (pairs_of[r].empty()) continue;
+            for (uint32_t t = 0; t < n_tiles; t++, k++)
+                for (uint32_t p : pairs_of[r]) cls[k & 7].push_back(make_uint2(t, p));
+        }
+        size_t longest = 0;
+        for (auto &v : cls) longest = std::max(longest, v.size());
+        flat.assign(longest * 8, make_uint2(~0u, 0u));
+        for (uint32_t x = 0; x < 8; x++)
+            for (size_t sl = 0; sl < cls[x].size(); sl++) flat[sl * 8 + x] = cls[x][sl];
+    }
+    if (flat.size() > L->cap) {
+        if (L->d) CE_HIP(ctx, hipFree(L->d));
+        L->d = nullptr;
+        L->cap = 0;
+        CE_HIP(ctx, hipMalloc(&L->d, flat.size() * sizeof(uint2)));
+        L->cap = (uint32_t)flat.size();
+    }
+    CE_HIP(ctx, hipMemcpyAsync(L->d, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is pageable and goes out of scope
+    L->len = (uint32_t)flat.size();
+    L->version = b->pair_ref_version;
+    L->pairs = n_pairs;
+    L->tiles = n_tiles;
+    return CE_OK;
+}
+
+void ce_free_xcd_list(ce_xcd_list *L)
+{
+    hipFree(L->d);
+    *L = ce_xcd_list{};
+}
+
 extern "C" {
 
 const char *ce_version(void) { return "codec-eval_amd 0.1.0 (gfx950)"; }

@@ -68,6 +68,12 @@ struct ce_ctx {
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ce_batch *> shape_pool;
 };
 
+// XCD-aware 1-D launch order for per-pair tile kernels (ce_build_xcd_list, ce_api.cpp): entry = (tile, pair)
+struct ce_xcd_list {
+    uint2 *d = nullptr;
+    uint32_t len = 0, cap = 0, version = ~0u, pairs = 0, tiles = 0;
+};
+
 struct ce_batch {
     ce_ctx *ctx = nullptr;
     uint32_t w = 0, h = 0, max_refs = 0, max_pairs = 0;
@@ -150,6 +156,7 @@ struct ce_batch {
     double *ds_part = nullptr; // [pairs][levels][2][blocks] partial sums (sum, abs-dev)
     double *ds_level_scores = nullptr;  // [pairs][levels]
     uint32_t ds_blocks = 0;
+    ce_xcd_list ds_work[CE_DSSIM_SCALES];  // k_dssim_compare's launch order, per level
     bool dssim_ready = false;
 
     // Butteraugli working set (butteraugli.hip): level 0 = full resolution, 1 = 2x-subsampled
@@ -166,6 +173,7 @@ struct ce_batch {
     double *ba_blk_sums = nullptr;
     double *ba_pnorm = nullptr;  // [pair] libjxl 3-norm of the last run
     uint32_t ba_blocks = 0;
+    ce_xcd_list ba_work[2];  // Malta's launch order, per resolution level
     bool ba_ready = false;
     const uint8_t *ba_ref_src = nullptr;  // reference slab the references' PsychoImage in ba_psy was built from
     uint32_t ba_ref_count = 0;
@@ -213,6 +221,8 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
 void ce_butteraugli_free(ce_batch *b);
 int ce_butteraugli_div_sweep(ce_ctx *ctx, uint64_t seed, uint64_t count, uint64_t *mismatches);
 int ce_calibrate_traffic(ce_ctx *ctx, size_t bytes);
+int ce_build_xcd_list(ce_batch *b, uint32_t n_pairs, uint32_t n_tiles, ce_xcd_list *list);
+void ce_free_xcd_list(ce_xcd_list *list);
 int ce_launch_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *d_rgb, float *d_rgba, size_t n_pixels);
 
 // host-side constant builders (ce_tables.cpp)

@@ -313,13 +313,17 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
                                                        const float *__restrict__ rmu, const float *__restrict__ rsq,
                                                        const uint32_t *__restrict__ pair_ref,
                                                        float *__restrict__ map, double *__restrict__ part, lvl_geom g,
-                                                       uint32_t max_refs, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
+                                                       uint32_t max_refs, uint32_t level, uint32_t n_levels, uint32_t n_blocks,
+                                                       const uint2 *__restrict__ work, uint32_t tiles_x)
 {
     __shared__ float M[3][CR * CR], T[3][CR * CR];
     __shared__ double s_red[TPB / 64];
-    const uint32_t p = blockIdx.z;
+    // XCD-aware 1-D launch (ce_build_xcd_list): the pairs of a reference run the same tile back to back on one XCD
+    const uint2 wi = work[blockIdx.x];
+    if (wi.x == ~0u) return;  // padding entry
+    const uint32_t p = wi.y;
     const int w = (int)g.w, h = (int)g.h;
-    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 2, gy0 = y0 - 2;
+    const int x0 = (int)(wi.x % tiles_x) * DT, y0 = (int)(wi.x / tiles_x) * DT, gx0 = x0 - 2, gy0 = y0 - 2;
     const size_t sa = (size_t)pair_ref[p] * 3 * g.plane, sb = (size_t)(max_refs + p) * 3 * g.plane;
     // The kernel waits on memory, not on arithmetic (round-2 counters: VALU busy 0.34, 0.65 of the wave-cycles parked),
     // in TWO rounds - the product tile, then mu / blur(img^2) behind two barriers.  The second round is requested here,
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
                            ? dssim_compare_stages<true>(M, T, st, map, g, p, x0, y0)
                            : dssim_compare_stages<false>(M, T, st, map, g, p, x0, y0);
     const double t = block_sum(val, s_red);
-    if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
+    if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + wi.x] = t;
 }
 
 // ---- avg = max(mean, 0)^(0.5^level): one block per pair reduces the SSIM partial sums in a fixed order ----
@@ -440,6 +444,7 @@ void ce_dssim_free(ce_batch *b)
     for (int l = 0; l < CE_DSSIM_SCALES; l++) {
         hipFree(b->ds_rimg[l]); hipFree(b->ds_rmu[l]); hipFree(b->ds_rsq[l]);
         b->ds_rimg[l] = b->ds_rmu[l] = b->ds_rsq[l] = nullptr;
+        ce_free_xcd_list(&b->ds_work[l]);
     }
     b->ds_ref_src = nullptr;
     hipFree(b->ds_part); hipFree(b->ds_level_scores);
@@ -532,9 +537,10 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                       ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img, b->ds_mu, b->ds_sq,
                       b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         // compare per pair
-        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(tiles.x, tiles.y, n_pairs), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
+        if ((rc = ce_build_xcd_list(b, n_pairs, tiles.x * tiles.y, &b->ds_work[l])) != CE_OK) return rc;
+        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
                   (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
-                  b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
+                  b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
                   (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
         const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);
