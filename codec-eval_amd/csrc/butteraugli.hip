@@ -277,7 +277,7 @@ __device__ __forceinline__ float fast_log2f(float x)
     const float t = m - 1.0f;
     const float yp = __builtin_fmaf(__builtin_fmaf(p2, t, p1), t, p0);
     const float yq = __builtin_fmaf(__builtin_fmaf(q2, t, q1), t, q0);
-    return yp / yq + (float)es;
+    return ce_div_noscale(yp, yq) + (float)es;  // yq in [0.67, 1.35], |yp| < 0.6 (ce_internal.h: the IEEE quotient, 8 instructions)
 }
 
 __device__ __forceinline__ float gamma_f(float v)
@@ -380,7 +380,8 @@ __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ re
             p0 = p0 > mn ? p0 : mn;
             p1v = p1v > mn ? p1v : mn;
             p2v = p2v > mn ? p2v : mn;
-            float s0 = gamma_f(p0) / p0, s1 = gamma_f(p1v) / p1v, s2 = gamma_f(p2v) / p2v;
+            // p >= 1e-4 (clamped above), gamma in [21, ~150]: IEEE quotients without the range-scaling steps (ce_internal.h)
+            float s0 = ce_div_noscale(gamma_f(p0), p0), s1 = ce_div_noscale(gamma_f(p1v), p1v), s2 = ce_div_noscale(gamma_f(p2v), p2v);
             s0 = s0 > mn ? s0 : mn;
             s1 = s1 > mn ? s1 : mn;
             s2 = s2 > mn ? s2 : mn;
@@ -638,15 +639,9 @@ struct malta_bands {
 // instead of 22, bit for bit (ce_debug_div_sweep checks it against operator/ on the device).
 __device__ __forceinline__ void div2_shared_rcp(float a0, float a1, float b, float &q0, float &q1)
 {
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r0, 1.0f);
-    const float r = __builtin_fmaf(e, r0, r0);
-    float q = a0 * r;
-    q = __builtin_fmaf(__builtin_fmaf(-b, q, a0), r, q);
-    q0 = __builtin_fmaf(__builtin_fmaf(-b, q, a0), r, q);
-    q = a1 * r;
-    q = __builtin_fmaf(__builtin_fmaf(-b, q, a1), r, q);
-    q1 = __builtin_fmaf(__builtin_fmaf(-b, q, a1), r, q);
+    const float r = ce_rcp_refined(b);  // ce_internal.h
+    q0 = ce_div_refined(a0, b, r);
+    q1 = ce_div_refined(a1, b, r);
 }
 
 __device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_params &mp)
@@ -1035,13 +1030,17 @@ __global__ __launch_bounds__(256) void k_div_sweep(uint64_t seed, uint64_t count
         x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
         x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
         x ^= x >> 31;
-        // b in [2^0, 2^31), a0 / a1 in [2^-8, 2^31): random mantissas, exponents from the hash
+        // b, a0, a1 in [2^-40, 2^40), either sign for the numerators, a zero numerator now and then: random mantissas,
+        // exponents from the hash - the range every call site of ce_div_noscale / div2_shared_rcp stays inside
         const uint32_t mb = (uint32_t)x & 0x7fffffu, ma = (uint32_t)(x >> 23) & 0x7fffffu, m2 = (uint32_t)(x >> 41) & 0x7fffffu;
-        const uint32_t eb = 127u + (uint32_t)((x >> 17) % 31u), ea = 119u + (uint32_t)((x >> 7) % 39u), e2 = 119u + (uint32_t)((x >> 3) % 39u);
-        const float b = __uint_as_float((eb << 23) | mb), a0 = __uint_as_float((ea << 23) | ma), a1 = __uint_as_float((e2 << 23) | m2);
+        const uint32_t eb = 87u + (uint32_t)((x >> 17) % 80u), ea = 87u + (uint32_t)((x >> 7) % 80u), e2 = 87u + (uint32_t)((x >> 3) % 80u);
+        const float b = __uint_as_float((eb << 23) | mb);
+        float a0 = __uint_as_float((ea << 23) | ma | ((uint32_t)(x >> 60) & 1u) << 31), a1 = __uint_as_float((e2 << 23) | m2);
+        if ((x >> 50 & 1023u) == 0) a0 = 0.0f;
         float q0, q1;
         div2_shared_rcp(a0, a1, b, q0, q1);
         bad += (__float_as_uint(q0) != __float_as_uint(a0 / b)) + (__float_as_uint(q1) != __float_as_uint(a1 / b));
+        bad += __float_as_uint(ce_div_noscale(a1, b)) != __float_as_uint(a1 / b);
     }
     if (bad) atomicAdd(out, bad);
 }

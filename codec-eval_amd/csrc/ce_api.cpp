@@ -612,18 +612,27 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     // L2 and halve each other's resident workgroups.  So the default keeps the chains back to back on the context's
     // stream (SSIMULACRA2 still overlaps its level-0 passes with its tail levels); CE_METRIC_STREAMS=fork restores the
     // forked schedule for A/B runs.
-    static const bool fork_chains = [] {
+    // fork mask: bit k = metric chain k (0 SSIMULACRA2, 1 DSSIM, 2 Butteraugli) runs on its own stream beside the others.
+    // CE_METRIC_STREAMS = "fork" (all three), "fork:dssim", "fork:ssim2,ba", ... ; unset / "serial" = none.
+    static const unsigned fork_mask_env = [] {
         const char *e = std::getenv("CE_METRIC_STREAMS");
-        return e && std::strcmp(e, "fork") == 0;
+        if (!e || std::strncmp(e, "fork", 4) != 0) return 0u;
+        if (e[4] != ':') return 7u;
+        unsigned m = 0;
+        if (std::strstr(e + 5, "ssim2")) m |= 1u;
+        if (std::strstr(e + 5, "dssim")) m |= 2u;
+        if (std::strstr(e + 5, "ba")) m |= 4u;
+        return m;
     }();
-    const bool fork = fork_chains && !ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1;
+    const unsigned fork_mask = (!ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1) ? fork_mask_env : 0u;
     hipStream_t base = ctx->stream;
-    if (fork) {
+    if (fork_mask) {
         if (!b->ev_fork) CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
         CE_HIP(ctx, hipEventRecord(b->ev_fork, base));
     }
+    unsigned joined = 0;
     auto chain = [&](int k, auto &&launch) -> int {
-        if (!fork) return launch();
+        if (!(fork_mask & (1u << k))) return launch();
         if (!b->metric_stream[k]) {
             CE_HIP(ctx, hipStreamCreateWithFlags(&b->metric_stream[k], hipStreamNonBlocking));
             CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming));
@@ -634,7 +643,7 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         ctx->stream = base;
         if (rc != CE_OK) return rc;
         CE_HIP(ctx, hipEventRecord(b->ev_join[k], b->metric_stream[k]));
-        CE_HIP(ctx, hipStreamWaitEvent(base, b->ev_join[k], 0));
+        joined |= 1u << k;  // the context's stream waits for it after every chain has been launched
         return CE_OK;
     };
     if (run_ssim2) {
@@ -649,6 +658,8 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         int rc = chain(2, [&] { return ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target); });
         if (rc != CE_OK) return rc;
     }
+    for (int k = 0; k < 3; k++)
+        if (joined & (1u << k)) CE_HIP(ctx, hipStreamWaitEvent(base, b->ev_join[k], 0));
     b->last_n_pairs = n_pairs;
     b->last_mask = metric_mask;
     CE_HIP(ctx, hipEventRecord(b->ev_run, ctx->stream));

@@ -205,6 +205,28 @@ void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream);
 #define CE_LAUNCH(ctx_, name_, kern_, grid_, block_, shmem_, ...)                                  \
     CE_LAUNCH_ON(ctx_, (ctx_)->stream, name_, kern_, grid_, block_, shmem_, __VA_ARGS__)
 
+#if defined(__HIPCC__)
+// Correctly rounded f32 quotients without the range-scaling steps of the compiler's expansion.  hipcc turns a / b into
+// v_div_scale x2, v_rcp, two fused steps refining the reciprocal, a product, two fused quotient corrections, v_div_fmas
+// and v_div_fixup (11 instructions).  When neither operand is zero-denominator / infinite / NaN / denormal and the
+// quotient is far from overflow and underflow - every call site below divides values between 2^-40 and 2^40 (a zero
+// numerator included) - v_div_scale returns its operands unchanged, v_div_fmas is a plain fma and v_div_fixup returns
+// the quotient, so the same arithmetic is 8 instructions, bit for bit.  ce_debug_div_sweep checks both forms against
+// operator/ on the device over exactly that range.
+__device__ __forceinline__ float ce_div_refined(float a, float b, float r)  // r = refined reciprocal of b
+{
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+__device__ __forceinline__ float ce_rcp_refined(float b)
+{
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float ce_div_noscale(float a, float b) { return ce_div_refined(a, b, ce_rcp_refined(b)); }
+#endif
+
 // ---- kernel launchers (one .hip file per metric) ---------------------------------------
 int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);
 size_t ce_pixel_bytes(int format);
