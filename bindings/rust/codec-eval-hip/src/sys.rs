@@ -14,6 +14,10 @@ pub struct ce_batch {
 pub struct ce_ref {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct ce_lut {
+    _private: [u8; 0],
+}
 
 pub const CE_OK: c_int = 0;
 pub const CE_ERR_DIM_MISMATCH: c_int = 1;
@@ -85,6 +89,8 @@ extern "C" {
                          intensity_target: c_float, out: *mut ce_scores) -> c_int;
     pub fn ce_estimate_batch_bytes(width: u32, height: u32, n_refs: u32, n_pairs: u32, metric_mask: u32) -> usize;
     pub fn ce_ctx_memory_info(ctx: *mut ce_ctx, free_bytes: *mut usize, total_bytes: *mut usize) -> c_int;
+    pub fn ce_eval_batch_lut(ctx: *mut ce_ctx, n: usize, pairs: *const ce_pair_desc, test_luts: *const *const ce_lut, metric_mask: u32,
+                             flags: u32, intensity_target: c_float, out: *mut ce_scores) -> c_int;
     pub fn ce_batch_create(ctx: *mut ce_ctx, width: u32, height: u32, max_refs: u32, max_pairs: u32, out: *mut *mut ce_batch) -> c_int;
     pub fn ce_batch_destroy(b: *mut ce_batch);
     pub fn ce_batch_set_reference(b: *mut ce_batch, ref_index: u32, rgb: *const u8, len: usize) -> c_int;
@@ -92,6 +98,12 @@ extern "C" {
     pub fn ce_batch_set_reference_fmt(b: *mut ce_batch, ref_index: u32, pixels: *const c_void, len: usize, format: c_int) -> c_int;
     pub fn ce_batch_set_test_fmt(b: *mut ce_batch, pair_index: u32, ref_index: u32, pixels: *const c_void, len: usize,
                                  format: c_int) -> c_int;
+    pub fn ce_lut_create(ctx: *mut ce_ctx, table: *const u8, table_len: usize, out: *mut *mut ce_lut) -> c_int;
+    pub fn ce_lut_destroy(lut: *mut ce_lut);
+    pub fn ce_batch_set_reference_lut(b: *mut ce_batch, ref_index: u32, pixels: *const c_void, len: usize, format: c_int,
+                                      lut: *const ce_lut) -> c_int;
+    pub fn ce_batch_set_test_lut(b: *mut ce_batch, pair_index: u32, ref_index: u32, pixels: *const c_void, len: usize, format: c_int,
+                                 lut: *const ce_lut) -> c_int;
     pub fn ce_batch_reference_slab(b: *mut ce_batch) -> *mut c_void;
     pub fn ce_batch_test_slab(b: *mut ce_batch) -> *mut c_void;
     pub fn ce_batch_bind_pair(b: *mut ce_batch, pair_index: u32, ref_index: u32) -> c_int;

@@ -122,12 +122,17 @@ _PROTOTYPES = [
     ("ce_eval_batch", _i, [_vp, _sz, C.POINTER(CePairDesc), _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_estimate_batch_bytes", _sz, [_u32, _u32, _u32, _u32, _u32]),
     ("ce_ctx_memory_info", _i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("ce_eval_batch_lut", _i, [_vp, _sz, C.POINTER(CePairDesc), C.POINTER(_vp), _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_batch_create", _i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("ce_batch_destroy", None, [_vp]),
     ("ce_batch_set_reference", _i, [_vp, _u32, _u8p, _sz]),
     ("ce_batch_set_test", _i, [_vp, _u32, _u32, _u8p, _sz]),
     ("ce_batch_set_reference_fmt", _i, [_vp, _u32, _vp, _sz, _i]),
     ("ce_batch_set_test_fmt", _i, [_vp, _u32, _u32, _vp, _sz, _i]),
+    ("ce_lut_create", _i, [_vp, _u8p, _sz, C.POINTER(_vp)]),
+    ("ce_lut_destroy", None, [_vp]),
+    ("ce_batch_set_reference_lut", _i, [_vp, _u32, _vp, _sz, _i, _vp]),
+    ("ce_batch_set_test_lut", _i, [_vp, _u32, _u32, _vp, _sz, _i, _vp]),
     ("ce_batch_reference_slab", _vp, [_vp]),
     ("ce_batch_test_slab", _vp, [_vp]),
     ("ce_batch_bind_pair", _i, [_vp, _u32, _u32]),
@@ -405,8 +410,9 @@ class Context:
         return MetricResult.from_c(s)
 
     def eval_batch(self, pairs: Sequence[tuple], config: MetricConfig,
-                   intensity_target: float = DEFAULT_INTENSITY_TARGET) -> List[CeScores]:
-        """pairs: (reference, test, width, height).  The (codec x quality) grid of session.rs:375-376."""
+                   intensity_target: float = DEFAULT_INTENSITY_TARGET, test_tables: Optional[Sequence] = None) -> List[CeScores]:
+        """pairs: (reference, test, width, height).  The (codec x quality) grid of session.rs:375-376.
+        test_tables: optional per-pair ColorTable (or None) applied to the distorted image on the device."""
         n = len(pairs)
         descs = (CePairDesc * n)()
         keep = []
@@ -415,7 +421,11 @@ class Context:
             keep.append((r, t))
             descs[i] = CePairDesc(r.ctypes.data, r.size, t.ctypes.data, t.size, w, h)
         out = (CeScores * n)()
-        self._check(lib().ce_eval_batch(self._h, n, descs, config.mask, config.flags, intensity_target, out))
+        if test_tables is not None:
+            luts = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in test_tables])
+            self._check(lib().ce_eval_batch_lut(self._h, n, descs, luts, config.mask, config.flags, intensity_target, out))
+        else:
+            self._check(lib().ce_eval_batch(self._h, n, descs, config.mask, config.flags, intensity_target, out))
         return list(out)
 
     # -- measurement hooks
@@ -447,6 +457,35 @@ class Context:
         ms = C.c_double()
         self._check(lib().ce_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+class ColorTable:
+    """ICC -> sRGB as a complete colour table on the device (ce_lut_*): `table[r, g, b] = transform(r, g, b)`, uint8,
+    shape (256, 256, 256, 3) - the host CMS evaluated once on the identity colour cube (`identity_cube()`), which
+    reproduces an 8-bit RGB -> 8-bit RGB transform such as the reference's (icc.rs:69-103) bit for bit."""
+
+    def __init__(self, ctx: "Context", table):
+        t = np.ascontiguousarray(np.asarray(table, dtype=np.uint8)).reshape(-1)
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        ctx._check(lib().ce_lut_create(ctx._h, t.ctypes.data, t.size, C.byref(self._h)))
+
+    @staticmethod
+    def identity_cube() -> np.ndarray:
+        """All 2^24 colours as an (2^24, 3) uint8 array in table order: feed it to the CMS, pass the result to ColorTable."""
+        v = np.arange(1 << 24, dtype=np.uint32)
+        return np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255], axis=1).astype(np.uint8)
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib().ce_lut_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Batch:
@@ -485,6 +524,15 @@ class Batch:
     def set_test_fmt(self, pair_index: int, ref_index: int, pixels, fmt: int):
         a = np.ascontiguousarray(pixels)
         self.ctx._check(lib().ce_batch_set_test_fmt(self._h, pair_index, ref_index, a.ctypes.data, a.nbytes, fmt))
+
+    # ... and through a colour table (ICC -> sRGB on the device)
+    def set_reference_lut(self, ref_index: int, pixels, fmt: int, table: Optional["ColorTable"]):
+        a = np.ascontiguousarray(pixels)
+        self.ctx._check(lib().ce_batch_set_reference_lut(self._h, ref_index, a.ctypes.data, a.nbytes, fmt, table._h if table else None))
+
+    def set_test_lut(self, pair_index: int, ref_index: int, pixels, fmt: int, table: Optional["ColorTable"]):
+        a = np.ascontiguousarray(pixels)
+        self.ctx._check(lib().ce_batch_set_test_lut(self._h, pair_index, ref_index, a.ctypes.data, a.nbytes, fmt, table._h if table else None))
 
     def bind_pair(self, pair_index: int, ref_index: int):
         self.ctx._check(lib().ce_batch_bind_pair(self._h, pair_index, ref_index))

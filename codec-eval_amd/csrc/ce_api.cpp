@@ -511,6 +511,73 @@ int ce_batch_set_reference_fmt(ce_batch *b, uint32_t ref_index, const void *pixe
     return upload_fmt(b, b->d_refs + (size_t)ref_index * b->img_bytes, pixels, len, format);
 }
 
+// ---- ICC -> sRGB colour tables ----------------------------------------------------------------------------------------
+struct ce_lut {
+    ce_ctx *ctx;
+    uint32_t *d_table;  // [2^24] r | g << 8 | b << 16
+};
+
+int ce_lut_create(ce_ctx *ctx, const uint8_t *table, size_t table_len, ce_lut **out)
+{
+    if (!ctx || !table || !out) return CE_ERR_INVALID_ARG;
+    *out = nullptr;
+    const size_t want = (size_t)3 << 24;
+    if (table_len != want)
+        return fail(ctx, CE_ERR_BAD_LENGTH, "Invalid colour table size: expected " + std::to_string(want) + " bytes, got " + std::to_string(table_len));
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    uint8_t *d_packed = nullptr;
+    uint32_t *d_table = nullptr;
+    CE_HIP(ctx, hipMalloc(&d_packed, want));
+    if (hipMalloc(&d_table, sizeof(uint32_t) << 24) != hipSuccess) {
+        hipFree(d_packed);
+        return fail(ctx, CE_ERR_BACKEND, "hipMalloc failed (colour table)");
+    }
+    int rc = CE_OK;
+    if (hipMemcpyAsync(d_packed, table, want, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "H2D failed (colour table)");
+    if (rc == CE_OK) rc = ce_launch_lut_expand(ctx, ctx->stream, d_packed, d_table);
+    if (rc == CE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "sync failed (colour table)");
+    hipFree(d_packed);
+    if (rc != CE_OK) {
+        hipFree(d_table);
+        return rc;
+    }
+    *out = new ce_lut{ctx, d_table};
+    return CE_OK;
+}
+
+void ce_lut_destroy(ce_lut *lut)
+{
+    if (!lut) return;
+    hipSetDevice(lut->ctx->device);
+    hipStreamSynchronize(lut->ctx->stream);
+    hipFree(lut->d_table);
+    delete lut;
+}
+
+// the table runs on the batch's upload stream, behind the copy (and the format conversion) of the same image
+static int apply_lut(ce_batch *b, uint8_t *slot, const ce_lut *lut)
+{
+    if (!lut) return CE_OK;
+    if (lut->ctx->device != b->ctx->device) return fail(b->ctx, CE_ERR_INVALID_ARG, "colour table and batch are on different devices");
+    // the table was built on its context's stream and ce_lut_create synchronised: it is complete
+    return ce_launch_lut_apply(b->ctx, b->up_stream, slot, lut->d_table, (size_t)b->w * b->h);
+}
+
+int ce_batch_set_reference_lut(ce_batch *b, uint32_t ref_index, const void *pixels, size_t len, int format, const ce_lut *lut)
+{
+    int rc = ce_batch_set_reference_fmt(b, ref_index, pixels, len, format);
+    if (rc != CE_OK) return rc;
+    return apply_lut(b, b->d_refs + (size_t)ref_index * b->img_bytes, lut);
+}
+
+int ce_batch_set_test_lut(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const void *pixels, size_t len, int format,
+                          const ce_lut *lut)
+{
+    int rc = ce_batch_set_test_fmt(b, pair_index, ref_index, pixels, len, format);
+    if (rc != CE_OK) return rc;
+    return apply_lut(b, b->d_tests + (size_t)pair_index * b->img_bytes, lut);
+}
+
 int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index)
 {
     if (!b) return CE_ERR_INVALID_ARG;
@@ -822,6 +889,12 @@ static int shape_batch(ce_ctx *ctx, uint32_t w, uint32_t h, uint32_t need_pairs,
 int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t metric_mask, uint32_t flags,
                   float intensity_target, ce_scores *out)
 {
+    return ce_eval_batch_lut(ctx, n, pairs, nullptr, metric_mask, flags, intensity_target, out);
+}
+
+int ce_eval_batch_lut(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, const ce_lut *const *test_luts, uint32_t metric_mask,
+                      uint32_t flags, float intensity_target, ce_scores *out)
+{
     if (!ctx || (!pairs && n) || (!out && n)) return CE_ERR_INVALID_ARG;
     // bucket by shape (Kodak mixes 768x512 and 512x768); invalid items never reach the device
     std::map<std::pair<uint32_t, uint32_t>, std::vector<size_t>> buckets;
@@ -927,6 +1000,12 @@ int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t met
             invalidate_reference_state(b);
             rc = upload_many(b, jobs);
             if (rc != CE_OK) return rc;
+            if (test_luts)  // ICC -> sRGB of the decoded images, on the upload stream behind their copies (icc.rs:69-103)
+                for (uint32_t kk = 0; kk < k; kk++)
+                    if (const ce_lut *lut = test_luts[ch.items[kk]]) {
+                        rc = apply_lut(b, b->d_tests + (size_t)kk * b->img_bytes, lut);
+                        if (rc != CE_OK) return rc;
+                    }
             rc = ce_batch_launch(b, k, metric_mask, flags, intensity_target);
             if (rc != CE_OK) return rc;
             chunks.push_back(std::move(ch));

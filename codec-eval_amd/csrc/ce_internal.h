@@ -231,6 +231,8 @@ __device__ __forceinline__ float ce_div_noscale(float a, float b) { return ce_di
 int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs);
 size_t ce_pixel_bytes(int format);
 int ce_launch_ingest(ce_ctx *ctx, hipStream_t stream, int format, const void *d_src, uint8_t *d_dst, size_t n_pixels);
+int ce_launch_lut_expand(ce_ctx *ctx, hipStream_t stream, const uint8_t *d_packed, uint32_t *d_table);
+int ce_launch_lut_apply(ce_ctx *ctx, hipStream_t stream, uint8_t *d_rgb, const uint32_t *d_table, size_t n_pixels);
 int ce_ssim2_prepare(ce_batch *b);
 void ce_ssim2_free(ce_batch *b);
 int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs);

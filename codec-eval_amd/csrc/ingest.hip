@@ -35,7 +35,43 @@ __global__ __launch_bounds__(256) void k_ingest(const void *__restrict__ src, ui
     }
 }
 
+// ---- ICC -> sRGB as a complete colour table (include/ce_metrics.h: ce_lut_*) ------------------------------------------
+// the host's packed 3-byte table -> one dword per colour (r | g << 8 | b << 16), so a lookup is one aligned 4-byte gather
+__global__ __launch_bounds__(256) void k_lut_expand(const uint8_t *__restrict__ packed, uint32_t *__restrict__ table, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        table[i] = (uint32_t)packed[3 * (size_t)i] | ((uint32_t)packed[3 * (size_t)i + 1] << 8) | ((uint32_t)packed[3 * (size_t)i + 2] << 16);
+}
+
+// in place on one packed RGB8 image of the slab: pixel -> table[(r << 16) | (g << 8) | b]
+__global__ __launch_bounds__(256) void k_lut_apply(uint8_t *__restrict__ rgb, const uint32_t *__restrict__ table, size_t n_pixels)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pixels; i += (size_t)gridDim.x * blockDim.x) {
+        uint8_t *p = rgb + 3 * i;
+        const uint32_t v = table[((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | (uint32_t)p[2]];
+        p[0] = (uint8_t)v;
+        p[1] = (uint8_t)(v >> 8);
+        p[2] = (uint8_t)(v >> 16);
+    }
+}
+
 }  // namespace
+
+int ce_launch_lut_expand(ce_ctx *ctx, hipStream_t stream, const uint8_t *d_packed, uint32_t *d_table)
+{
+    CE_LAUNCH_ON(ctx, stream, "lut_expand", k_lut_expand, dim3(8192), dim3(256), 0, d_packed, d_table, 1u << 24);
+    CE_HIP(ctx, hipGetLastError());
+    return CE_OK;
+}
+
+int ce_launch_lut_apply(ce_ctx *ctx, hipStream_t stream, uint8_t *d_rgb, const uint32_t *d_table, size_t n_pixels)
+{
+    if (n_pixels == 0) return CE_OK;
+    const dim3 grid((uint32_t)std::min<size_t>((n_pixels + 255) / 256, 8192)), block(256);
+    CE_LAUNCH_ON(ctx, stream, "lut_apply", k_lut_apply, grid, block, 0, d_rgb, d_table, n_pixels);
+    CE_HIP(ctx, hipGetLastError());
+    return CE_OK;
+}
 
 size_t ce_pixel_bytes(int format)
 {

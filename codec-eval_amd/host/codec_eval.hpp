@@ -192,8 +192,13 @@ struct ImageData {
     enum class Format { Rgb8, Rgba8 } format = Format::Rgb8;
     std::vector<uint8_t> data;
     size_t width = 0, height = 0;
-    static ImageData rgb(std::vector<uint8_t> d, size_t w, size_t h) { return {Format::Rgb8, std::move(d), w, h}; }
-    static ImageData rgba(std::vector<uint8_t> d, size_t w, size_t h) { return {Format::Rgba8, std::move(d), w, h}; }
+    std::optional<std::vector<uint8_t>> icc_profile;  // RgbSliceWithIcc, session.rs:60-77
+    static ImageData rgb(std::vector<uint8_t> d, size_t w, size_t h) { return {Format::Rgb8, std::move(d), w, h, std::nullopt}; }
+    static ImageData rgba(std::vector<uint8_t> d, size_t w, size_t h) { return {Format::Rgba8, std::move(d), w, h, std::nullopt}; }
+    static ImageData rgb_with_icc(std::vector<uint8_t> d, size_t w, size_t h, std::vector<uint8_t> icc)
+    {
+        return {Format::Rgb8, std::move(d), w, h, std::move(icc)};
+    }
     // to_rgb8_vec, session.rs:98-117: alpha is dropped
     std::vector<uint8_t> to_rgb8_vec() const
     {
@@ -203,6 +208,34 @@ struct ImageData {
         for (size_t i = 0; i + 3 < data.size(); i += 4) out.insert(out.end(), {data[i], data[i + 1], data[i + 2]});
         return out;
     }
+};
+
+// ---- ICC -> sRGB (src/metrics/icc.rs:69-103) as a device colour table --------------------------------------------------
+// Cms: the host's colour management, 8-bit RGB -> 8-bit RGB for one profile (the reference's default build uses moxcms).
+// It is evaluated once per profile on the identity colour cube; the table then lives on the device (ce_lut_*).
+using Cms = std::function<std::vector<uint8_t>(const std::vector<uint8_t> &icc_profile, const std::vector<uint8_t> &rgb)>;
+
+class HipColorTable {
+public:
+    HipColorTable(const HipBackend &be, const Cms &cms, const std::vector<uint8_t> &icc_profile)
+    {
+        std::vector<uint8_t> cube((size_t)3 << 24);
+        for (uint32_t v = 0; v < (1u << 24); v++) {
+            cube[3 * (size_t)v] = (uint8_t)(v >> 16);
+            cube[3 * (size_t)v + 1] = (uint8_t)(v >> 8);
+            cube[3 * (size_t)v + 2] = (uint8_t)v;
+        }
+        const std::vector<uint8_t> table = cms(icc_profile, cube);
+        if (ce_lut_create(be.ctx(), table.data(), table.size(), &lut_) != CE_OK)
+            throw Error(Error::Kind::MetricCalculation, "Metric calculation failed: ICC: Failed to create ICC transform: " + be.last_error());
+    }
+    ~HipColorTable() { ce_lut_destroy(lut_); }
+    HipColorTable(const HipColorTable &) = delete;
+    HipColorTable &operator=(const HipColorTable &) = delete;
+    const ce_lut *get() const { return lut_; }
+
+private:
+    ce_lut *lut_ = nullptr;
 };
 
 struct EncodeRequest {  // session.rs:151-177
@@ -249,10 +282,18 @@ public:
         return *this;
     }
     size_t codec_count() const { return codecs_.size(); }
+    // the host's ICC -> sRGB transform for tagged DECODED images (session.rs:394); without one a tagged image fails like
+    // a build without the `icc` feature (icc.rs:105-113).  Tables are built once per distinct profile and kept.
+    EvalSession &set_cms(Cms cms)
+    {
+        cms_ = std::move(cms);
+        return *this;
+    }
 
     // evaluate_image, session.rs:368-434
     ImageReport evaluate_image(const std::string &name, const ImageData &image) const
     {
+        std::vector<const ce_lut *> luts;
         ImageReport report{name, (uint32_t)image.width, (uint32_t)image.height, {}};
         const std::vector<uint8_t> reference_rgb = image.to_rgb8_vec();
         std::vector<std::vector<uint8_t>> decoded;  // kept alive until the batch has run
@@ -276,7 +317,8 @@ public:
                     const auto d0 = std::chrono::steady_clock::now();
                     const ImageData dec = codec.decode(encoded);
                     r.decode_time = std::chrono::steady_clock::now() - d0;
-                    decoded.push_back(dec.to_rgb8_vec());  // sRGB assumed (ICC transforms stay on the host, icc.rs:69)
+                    decoded.push_back(dec.to_rgb8_vec());
+                    luts.push_back(table_for(dec));  // to_rgb8_srgb (session.rs:394) runs on the device
                     result_of_pair.push_back(report.results.size());
                 }
                 report.results.push_back(std::move(r));
@@ -287,8 +329,8 @@ public:
                 pairs[i] = {reference_rgb.data(), reference_rgb.size(), decoded[i].data(), decoded[i].size(), (uint32_t)image.width,
                             (uint32_t)image.height};
             std::vector<ce_scores> scores(decoded.size());
-            const int rc = ce_eval_batch(be_->ctx(), pairs.size(), pairs.data(), config_.metrics.mask(), config_.metrics.flags(),
-                                         config_.intensity_target, scores.data());
+            const int rc = ce_eval_batch_lut(be_->ctx(), pairs.size(), pairs.data(), luts.data(), config_.metrics.mask(),
+                                             config_.metrics.flags(), config_.intensity_target, scores.data());
             detail::check(*be_, rc, "batch", image.width, image.height, reference_rgb.size());
             for (size_t i = 0; i < decoded.size(); i++) {
                 detail::check(*be_, scores[i].status, "metric", image.width, image.height, decoded[i].size());  // `?` in :394-396
@@ -306,9 +348,20 @@ private:
         EncodeFn encode;
         DecodeFn decode;
     };
+    const ce_lut *table_for(const ImageData &decoded) const
+    {
+        if (!decoded.icc_profile) return nullptr;  // ColorProfile::Srgb: a plain copy (icc.rs:73)
+        if (!cms_)
+            throw Error(Error::Kind::MetricCalculation, "Metric calculation failed: ICC: ICC profile support requires the 'icc' feature");
+        auto it = tables_.find(*decoded.icc_profile);
+        if (it == tables_.end()) it = tables_.emplace(*decoded.icc_profile, std::make_unique<HipColorTable>(*be_, cms_, *decoded.icc_profile)).first;
+        return it->second->get();
+    }
     std::shared_ptr<HipBackend> be_;
     EvalConfig config_;
     std::vector<CodecEntry> codecs_;
+    Cms cms_;
+    mutable std::map<std::vector<uint8_t>, std::unique_ptr<HipColorTable>> tables_;
 };
 
 // ---- crates/codec-iter: the SSIMULACRA2 plug point ---------------------------------------------------------

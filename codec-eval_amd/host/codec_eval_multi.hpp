@@ -78,6 +78,7 @@ struct ReferenceJob {
     const uint8_t *reference = nullptr;  // packed RGB8, borrowed for the duration of run()
     uint32_t width = 0, height = 0;
     std::vector<const uint8_t *> tests;  // the distorted images of this reference (same shape), borrowed
+    std::vector<int> test_profile;       // optional, per test: index into the profile list given to run(), -1 = untagged (sRGB)
     std::vector<ce_scores> scores;       // filled by run(): one per test, in the order of `tests`
     int device = -1;                     // which device scored it (diagnostics; never affects the values)
 };
@@ -111,10 +112,16 @@ public:
 
     // Scores every job.  jobs[i].scores is filled for every i; results do not depend on the device count or on which
     // device took which job.  Throws the first worker's error after all workers have stopped.
+    // profiles + cms: the ICC profiles the jobs' test_profile indices refer to and the host colour management; every
+    // worker builds the colour table of a profile on ITS device the first time it meets it (a table belongs to a device)
     MultiDeviceStats run(std::vector<ReferenceJob> &jobs, const MetricConfig &metrics, float intensity_target = CE_DEFAULT_INTENSITY_TARGET,
-                         size_t device_budget_bytes = 0)
+                         size_t device_budget_bytes = 0, const std::vector<std::vector<uint8_t>> *profiles = nullptr, const Cms *cms = nullptr)
     {
         const int n_workers = devices();
+        profiles_ = profiles;
+        cms_ = cms;
+        tables_.clear();
+        tables_.resize((size_t)n_workers);
         std::vector<size_t> load(jobs.size()), cost(jobs.size());
         for (size_t i = 0; i < jobs.size(); i++) {
             load[i] = (size_t)jobs[i].width * jobs[i].height * std::max<size_t>(jobs[i].tests.size(), 1);
@@ -177,13 +184,26 @@ private:
     int score_chunk(int w, std::vector<ReferenceJob *> &chunk, const MetricConfig &metrics, float intensity_target)
     {
         std::vector<ce_pair_desc> pairs;
+        std::vector<const ce_lut *> luts;
         for (ReferenceJob *j : chunk) {
             const size_t len = (size_t)j->width * j->height * 3;
-            for (const uint8_t *t : j->tests) pairs.push_back({j->reference, len, t, len, j->width, j->height});
+            for (size_t t = 0; t < j->tests.size(); t++) {
+                pairs.push_back({j->reference, len, j->tests[t], len, j->width, j->height});
+                const int pi = t < j->test_profile.size() ? j->test_profile[t] : -1;
+                const ce_lut *lut = nullptr;
+                if (pi >= 0) {
+                    if (!profiles_ || !cms_ || (size_t)pi >= profiles_->size()) return CE_ERR_INVALID_ARG;
+                    auto &slot = tables_[(size_t)w][pi];
+                    if (!slot) slot = std::make_unique<HipColorTable>(*backends_[(size_t)w], *cms_, (*profiles_)[(size_t)pi]);
+                    lut = slot->get();
+                }
+                luts.push_back(lut);
+            }
         }
         if (pairs.empty()) return CE_OK;
         std::vector<ce_scores> out(pairs.size());
-        const int rc = ce_eval_batch(backends_[(size_t)w]->ctx(), pairs.size(), pairs.data(), metrics.mask(), metrics.flags(), intensity_target, out.data());
+        const int rc = ce_eval_batch_lut(backends_[(size_t)w]->ctx(), pairs.size(), pairs.data(), luts.data(), metrics.mask(), metrics.flags(),
+                                         intensity_target, out.data());
         if (rc != CE_OK) return rc;
         size_t k = 0;
         for (ReferenceJob *j : chunk)
@@ -194,6 +214,9 @@ private:
     std::vector<std::shared_ptr<HipBackend>> backends_;
     int mock_workers_ = 0;
     ChunkScorer scorer_;
+    const std::vector<std::vector<uint8_t>> *profiles_ = nullptr;
+    const Cms *cms_ = nullptr;
+    std::vector<std::map<int, std::unique_ptr<HipColorTable>>> tables_;  // [worker][profile index], each touched by its worker only
 };
 
 // ---- EvalSession over all devices ------------------------------------------------------------------------------------------
@@ -214,6 +237,11 @@ public:
         return *this;
     }
     size_t codec_count() const { return codecs_.size(); }
+    MultiDeviceEvalSession &set_cms(Cms cms)  // EvalSession::set_cms: ICC -> sRGB of tagged decoded images (session.rs:394)
+    {
+        cms_ = std::move(cms);
+        return *this;
+    }
 
     std::vector<ImageReport> evaluate_corpus(const std::vector<std::pair<std::string, ImageData>> &images, MultiDeviceStats *stats = nullptr) const
     {
@@ -221,6 +249,8 @@ public:
         std::vector<std::vector<uint8_t>> references(images.size());
         std::vector<std::vector<std::vector<uint8_t>>> decoded(images.size());
         std::vector<std::vector<size_t>> row_of_cell(images.size());
+        std::vector<std::vector<int>> profile_of_cell(images.size());
+        std::vector<std::vector<uint8_t>> profiles;  // distinct ICC profiles met among the decoded images
         for (size_t i = 0; i < images.size(); i++) {
             const ImageData &image = images[i].second;
             reports[i] = ImageReport{images[i].first, (uint32_t)image.width, (uint32_t)image.height, {}};
@@ -248,6 +278,15 @@ public:
                                                                             std::to_string(image.height) + "), got (" + std::to_string(dec.width) + ", " +
                                                                             std::to_string(dec.height) + ")");
                         decoded[i].push_back(dec.to_rgb8_vec());
+                        int pi = -1;
+                        if (dec.icc_profile) {
+                            if (!cms_)
+                                throw Error(Error::Kind::MetricCalculation, "Metric calculation failed: ICC: ICC profile support requires the 'icc' feature");
+                            const auto it = std::find(profiles.begin(), profiles.end(), *dec.icc_profile);
+                            pi = (int)(it - profiles.begin());
+                            if (it == profiles.end()) profiles.push_back(*dec.icc_profile);
+                        }
+                        profile_of_cell[i].push_back(pi);
                         row_of_cell[i].push_back(reports[i].results.size());
                     }
                     reports[i].results.push_back(std::move(r));
@@ -259,8 +298,9 @@ public:
             jobs[i].width = (uint32_t)images[i].second.width;
             jobs[i].height = (uint32_t)images[i].second.height;
             for (const auto &d : decoded[i]) jobs[i].tests.push_back(d.data());
+            jobs[i].test_profile = profile_of_cell[i];
         }
-        const MultiDeviceStats st = pool_->run(jobs, config_.metrics, config_.intensity_target);
+        const MultiDeviceStats st = pool_->run(jobs, config_.metrics, config_.intensity_target, 0, &profiles, cms_ ? &cms_ : nullptr);
         if (stats) *stats = st;
         for (size_t i = 0; i < images.size(); i++)
             for (size_t c = 0; c < jobs[i].scores.size(); c++) {
@@ -284,6 +324,7 @@ private:
     std::shared_ptr<DevicePool> pool_;
     EvalConfig config_;
     std::vector<CodecEntry> codecs_;
+    Cms cms_;
 };
 
 }  // namespace eval

@@ -16,7 +16,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import (PIXEL_RGB8, PIXEL_RGBA8, Batch, CodecEvalError, Context, DimensionMismatch, MetricCalculation,
+from . import (PIXEL_RGB8, PIXEL_RGBA8, Batch, CodecEvalError, ColorTable, Context, DimensionMismatch, MetricCalculation,
                MetricConfig, MetricResult, _error_obj, estimate_batch_bytes, CE_ERR_BACKEND)
 from . import reports as R
 
@@ -49,13 +49,20 @@ class ImageData:
             return self.data
         return np.ascontiguousarray(self.data.reshape(-1, 4)[:, :3]).reshape(-1)
 
-    def to_rgb8_srgb(self) -> np.ndarray:  # session.rs:143-147 -> metrics/icc.rs:69-113
-        self._check_profile()
-        return self.to_rgb8_vec()
+    def to_rgb8_srgb(self, cms: Optional[Callable[[bytes, np.ndarray], np.ndarray]] = None) -> np.ndarray:
+        """session.rs:143-147 -> transform_to_srgb, metrics/icc.rs:69-113: on the HOST (the session itself applies the
+        profile on the device through a colour table).  `cms(profile_bytes, rgb_nx3_u8) -> rgb_nx3_u8` is the colour
+        management to use (the reference's is moxcms); without one a tagged image fails like a build without `icc`."""
+        rgb = self.to_rgb8_vec()
+        if self.icc_profile is None:
+            return rgb
+        if cms is None:
+            self._check_profile()
+        return np.ascontiguousarray(cms(self.icc_profile, rgb.reshape(-1, 3)), dtype=np.uint8).reshape(-1)
 
     def _check_profile(self):
         if self.icc_profile is not None:
-            # the reference without its `icc` feature (icc.rs:105-113); moxcms is not part of this path
+            # the reference built without its `icc` feature (icc.rs:105-113): no colour management available
             raise MetricCalculation(CE_ERR_BACKEND, "Metric calculation failed: ICC: ICC profile support requires the 'icc' feature")
 
     @property
@@ -136,15 +143,41 @@ class _CodecEntry:
 class EvalSession:
     """session.rs:309-497.  One session = one device context; `evaluate_image` may be called for any shape."""
 
-    def __init__(self, config: EvalConfig, ctx: Optional[Context] = None, device: int = 0):
+    def __init__(self, config: EvalConfig, ctx: Optional[Context] = None, device: int = 0,
+                 cms: Optional[Callable[[bytes, np.ndarray], np.ndarray]] = None):
+        """cms(profile_bytes, rgb (n, 3) uint8) -> (n, 3) uint8: the host's ICC -> sRGB transform (the reference's default
+        build uses moxcms, icc.rs:69-103).  It is evaluated ONCE per distinct profile on the identity colour cube; the
+        resulting 2^24-entry table lives on the device and is applied to every decoded image tagged with that profile
+        (session.rs:394: only DECODED images go through to_rgb8_srgb, the source image does not).  Without a cms a tagged
+        decoded image raises what a build without the `icc` feature raises."""
         self.config = config
         self.ctx = ctx or Context(device)
         self._own_ctx = ctx is None
         self._codecs: List[_CodecEntry] = []
+        self._cms = cms
+        self._tables: Dict[bytes, ColorTable] = {}
 
     def close(self):
+        for t in self._tables.values():
+            t.close()
+        self._tables.clear()
         if self._own_ctx:
             self.ctx.close()
+
+    def _table_for(self, image: ImageData) -> Optional[ColorTable]:
+        """The device colour table of a decoded image's profile (None for untagged = sRGB images, icc.rs:73)."""
+        if image.icc_profile is None:
+            return None
+        if self._cms is None:
+            image._check_profile()
+        key = bytes(image.icc_profile)
+        t = self._tables.get(key)
+        if t is None:
+            out = np.asarray(self._cms(key, ColorTable.identity_cube()), dtype=np.uint8)
+            if out.shape != (1 << 24, 3):
+                raise MetricCalculation(CE_ERR_BACKEND, f"Metric calculation failed: ICC: Failed to apply ICC transform: the cms returned shape {out.shape}")
+            t = self._tables[key] = ColorTable(self.ctx, out)
+        return t
 
     def add_codec(self, id: str, version: str, encode: EncodeFn) -> "EvalSession":  # :325-334
         self._codecs.append(_CodecEntry(id, version, encode, None))
@@ -177,7 +210,8 @@ class EvalSession:
                     t0 = time.perf_counter()
                     decoded = codec.decode(encoded)
                     row.decode_time_ms = int((time.perf_counter() - t0) * 1000)
-                    decoded._check_profile()  # to_rgb8_srgb's failure mode, before anything reaches the device
+                    if self._cms is None:
+                        decoded._check_profile()  # to_rgb8_srgb's failure mode without colour management, before anything reaches the device
                     pending.append((len(report.results), decoded))
                 report.results.append(row)
         return report, pending
@@ -224,7 +258,7 @@ class EvalSession:
                 for row_index, decoded in pending:
                     if (decoded.width, decoded.height) != (w, h):  # calculate_metrics' length check, ssimulacra2.rs:65-70
                         raise DimensionMismatch(1, f"Dimension mismatch: expected ({w}, {h}), got ({decoded.width}, {decoded.height})")
-                    batch.set_test_fmt(k, ri, decoded.data, decoded.pixel_format)
+                    batch.set_test_lut(k, ri, decoded.data, decoded.pixel_format, self._table_for(decoded))  # to_rgb8_srgb, session.rs:394
                     rows.append((report, row_index))
                     k += 1
             scores = batch.run(n_pairs, cfg)
@@ -239,7 +273,7 @@ class EvalSession:
             row.perception = m.perception_level()  # session.rs:407
 
     def evaluate_image(self, name: str, image: ImageData) -> R.ImageReport:  # session.rs:368-434
-        image._check_profile()
+        # the source image enters as to_rgb8_vec() (session.rs:373): its own profile, if any, is NOT applied
         report, pending = self._sweep(name, image)
         self._score([(image, report, pending)])
         return report
@@ -257,7 +291,6 @@ class EvalSession:
         jobs = []
         for i in mine:
             img_name, image = images[i]
-            image._check_profile()
             report, pending = self._sweep(img_name, image)
             jobs.append((image, report, pending))
             corpus.images.append(report)

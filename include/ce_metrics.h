@@ -38,6 +38,7 @@ extern "C" {
 typedef struct ce_ctx ce_ctx;     /* device + stream + scratch pool       */
 typedef struct ce_batch ce_batch; /* HBM-resident grid of (ref, test) pairs of one shape */
 typedef struct ce_ref ce_ref;     /* one reference image held on device   */
+typedef struct ce_lut ce_lut;     /* one colour transform (ICC -> sRGB) held on device as a 2^24-entry table */
 
 enum ce_status {
     CE_OK = 0,
@@ -133,6 +134,10 @@ int ce_eval_pair(ce_ctx *ctx, const uint8_t *reference, size_t reference_len, co
  * call itself could not run. */
 int ce_eval_batch(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, uint32_t metric_mask, uint32_t flags,
                   float intensity_target, ce_scores *out);
+/* the same with a colour table per pair for the DISTORTED image (NULL entries / a NULL array: none): the decoded image's
+ * ICC -> sRGB step of evaluate_image (session.rs:394, ImageData::to_rgb8_srgb) runs on the device - see ce_lut_create */
+int ce_eval_batch_lut(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, const ce_lut *const *test_luts, uint32_t metric_mask,
+                      uint32_t flags, float intensity_target, ce_scores *out);
 
 /* Memory planning for callers that size their own batches (EvalSession::evaluate_corpus streams a corpus through
  * batches that fit the device): an upper estimate of the device bytes a batch of this shape holds once the metrics
@@ -163,6 +168,19 @@ enum {
 };
 int ce_batch_set_reference_fmt(ce_batch *b, uint32_t ref_index, const void *pixels, size_t len, int format);
 int ce_batch_set_test_fmt(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const void *pixels, size_t len, int format);
+/* ICC -> sRGB on the device, EXACTLY (transform_to_srgb, src/metrics/icc.rs:69-103, called on every decoded image at
+ * src/eval/session.rs:394 through ImageData::to_rgb8_srgb).  The reference's transform (moxcms, 8-bit RGB -> 8-bit RGB)
+ * is a pure function of a pixel's three bytes, so the table of its outputs on all 2^24 colours reproduces it bit for bit:
+ * the host runs ITS colour management once per profile over the identity colour cube (50 MB, tens of milliseconds) and
+ * the device applies the table to every decoded image of that profile - no per-pixel colour management on the host and
+ * no interpolation error.  table[((r << 16) | (g << 8) | b) * 3 + c] = channel c of the transformed colour;
+ * table_len must be 3 * 2^24.  A table belongs to its context's device and must be destroyed before the context. */
+int ce_lut_create(ce_ctx *ctx, const uint8_t *table, size_t table_len, ce_lut **out);
+void ce_lut_destroy(ce_lut *lut);
+/* ce_batch_set_{reference,test}_fmt followed by the table, all on the device (lut == NULL: no transform) */
+int ce_batch_set_reference_lut(ce_batch *b, uint32_t ref_index, const void *pixels, size_t len, int format, const ce_lut *lut);
+int ce_batch_set_test_lut(ce_batch *b, uint32_t pair_index, uint32_t ref_index, const void *pixels, size_t len, int format,
+                          const ce_lut *lut);
 /* device pointers of the packed u8 slabs ([max_refs][h][w][3], [max_pairs][h][w][3]) so a caller that
  * already has pixels in HBM (e.g. a GPU decoder) can write them in place */
 void *ce_batch_reference_slab(ce_batch *b);

@@ -296,6 +296,48 @@ static void with_gpu()
         CHECK(rep.results[i].codec_id == "size-only" && !rep.results[i].metrics.psnr && !rep.results[i].perception);
     }
 
+    // ICC: a tagged decoded image goes through the host CMS's colour table on the device; scores equal those of pixels
+    // transformed on the host with the same CMS; without a CMS it fails like a build without the `icc` feature
+    {
+        const eval::Cms cms = [](const std::vector<uint8_t> &profile, const std::vector<uint8_t> &rgb) {
+            std::vector<uint8_t> out(rgb.size());
+            const uint8_t k = (uint8_t)profile.size();
+            for (size_t i = 0; i + 2 < rgb.size(); i += 3) {  // a cross-channel, non-linear 8-bit -> 8-bit map
+                out[i] = (uint8_t)((rgb[i] * 3 + rgb[i + 1] + k) / 4);
+                out[i + 1] = (uint8_t)(255 - (255 - rgb[i + 1]) * (255 - rgb[i + 1]) / 255);
+                out[i + 2] = (uint8_t)((rgb[i + 2] + rgb[i]) / 2);
+            }
+            return out;
+        };
+        eval::EvalConfig icfg;
+        icfg.metrics = MetricConfig::all();
+        icfg.quality_levels = {60.0};
+        const std::vector<uint8_t> profile = {1, 2, 3, 4, 5};
+        auto tagged_decode = [&](const std::vector<uint8_t> &bytes) {
+            std::vector<uint8_t> d(bytes);
+            for (auto &v : d) v = (uint8_t)std::min(255, (v / 6) * 6 + 3);
+            return ImageData::rgb_with_icc(std::move(d), 96, 80, profile);
+        };
+        eval::EvalSession plain(be, icfg), managed(be, icfg);
+        plain.add_codec_with_decode("tagged", "1", encode, tagged_decode);
+        managed.add_codec_with_decode("tagged", "1", encode, tagged_decode).set_cms(cms);
+        bool no_cms = false;
+        try {
+            plain.evaluate_image("p.png", src);
+        } catch (const Error &e) {
+            no_cms = e.kind == Error::Kind::MetricCalculation && std::string(e.what()).find("requires the 'icc' feature") != std::string::npos;
+        }
+        CHECK(no_cms);
+        const eval::ImageReport irep = managed.evaluate_image("p.png", src);
+        const auto host_px = cms(profile, tagged_decode(src.to_rgb8_vec()).data);
+        const auto ref_px = src.to_rgb8_vec();
+        CHECK(irep.results.size() == 1);
+        CHECK(*irep.results[0].metrics.psnr == metrics::calculate_psnr(*be, ref_px, host_px, 96, 80));
+        CHECK(*irep.results[0].metrics.ssimulacra2 == metrics::calculate_ssimulacra2(*be, ref_px, host_px, 96, 80));
+        CHECK(*irep.results[0].metrics.dssim == metrics::calculate_dssim(*be, ref_px, host_px, 96, 80));
+        CHECK(*irep.results[0].metrics.butteraugli == metrics::calculate_butteraugli(*be, ref_px, host_px, 96, 80));
+    }
+
     // codec-iter's plug point (crates/codec-iter/src/eval.rs:56-149, gpu.rs:40-116): GpuSsim2::new(w, h) +
     // compute(), Ssimulacra2Reference::new + compare() over the quality sweep, Ssim2Backend dispatch.
     const auto a = src.to_rgb8_vec();
