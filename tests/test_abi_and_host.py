@@ -107,3 +107,30 @@ def test_perception_levels(ce):
     assert ce.perception_from_butteraugli(0.99) == "Imperceptible" and ce.perception_from_butteraugli(5.0) == "Degraded"
     assert ce.MetricResult(dssim=0.0001).perception_level() == "Imperceptible"
     assert ce.MetricResult().perception_level() is None
+
+
+def test_image_data_icc_semantics_on_the_host(ce):
+    """ImageData mirrors session.rs:25-149: to_rgb8_vec never applies a profile; to_rgb8_srgb applies it through the
+    caller's CMS (transform_to_srgb, icc.rs:69-103) and, without one, fails like a build without the `icc` feature."""
+    import importlib
+
+    import numpy as np
+    import pytest
+
+    S = importlib.import_module("codec-eval_amd.session")
+    px = (np.arange(4 * 3 * 3) % 256).astype(np.uint8)
+    plain, tagged = S.ImageData.rgb(px, 4, 3), S.ImageData.rgb_with_icc(px, 4, 3, b"profile")
+    assert np.array_equal(plain.to_rgb8_srgb(), px) and np.array_equal(tagged.to_rgb8_vec(), px)
+    with pytest.raises(ce.MetricCalculation, match="requires the 'icc' feature"):
+        tagged.to_rgb8_srgb()
+    seen = []
+
+    def cms(profile, rgb):
+        seen.append((profile, rgb.shape))
+        return 255 - rgb
+
+    assert np.array_equal(tagged.to_rgb8_srgb(cms), 255 - px) and seen == [(b"profile", (12, 3))]
+    assert np.array_equal(plain.to_rgb8_srgb(cms), px) and len(seen) == 1  # untagged = sRGB: a plain copy (icc.rs:73)
+    cube = ce.ColorTable.identity_cube()
+    assert cube.shape == (1 << 24, 3) and cube.dtype == np.uint8
+    assert cube[0].tolist() == [0, 0, 0] and cube[(7 << 16) | (9 << 8) | 11].tolist() == [7, 9, 11] and cube[-1].tolist() == [255, 255, 255]
