@@ -153,7 +153,7 @@ void ce_free_xcd_list(ce_xcd_list *L)
 
 extern "C" {
 
-const char *ce_version(void) { return "codec-eval_amd 0.1.0 (gfx950)"; }
+const char *ce_version(void) { return "codec-eval_amd 0.2.0 (gfx950)"; }
 
 int ce_device_count(void)
 {
