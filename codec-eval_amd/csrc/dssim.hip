@@ -100,6 +100,14 @@ struct lvl_geom {
 // Writes img, mu, sq (9 planes) for the tile; every intermediate lives in LDS only.
 constexpr int DT = 32, DR = DT + 8;
 
+// the elements of an R x R LDS region that lie at least M away from its border, TPB at a time: j runs over the compact
+// (R - 2M)^2 index space, so no lane of any iteration but the last is masked off (looping over all R * R elements with a
+// margin test leaves a third of the issue slots of the margin-3 stages empty, and the create kernels are VALU-bound)
+#define CE_MARGIN_LOOP(R, M, i, lx, ly)                                                                               \
+    for (int j_ = threadIdx.x, lx = j_ % ((R) - 2 * (M)) + (M), ly = j_ / ((R) - 2 * (M)) + (M), i = ly * (R) + lx;    \
+         j_ < ((R) - 2 * (M)) * ((R) - 2 * (M));                                                                       \
+         j_ += TPB, lx = j_ % ((R) - 2 * (M)) + (M), ly = j_ / ((R) - 2 * (M)) + (M), i = ly * (R) + lx)
+
 // stages S1..S4 of k_dssim_create on the LDS planes; IN = the block's whole 40x40 region is inside the image
 template <bool IN>
 __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], float *__restrict__ img, float *__restrict__ mu,
@@ -110,27 +118,24 @@ __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], floa
     // Six LDS planes are enough (38 KB, four blocks per CU instead of two): planes are reused as soon as their
     // contents are dead, and mu / sq are produced one after the other through the same three planes.
     // S1: chroma pre-blur pass 1 (margin 1): P1,P2 -> P3,P4
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 1 && lx < DR - 1 && ly >= 1 && ly < DR - 1 && (IN || inside(lx, ly))) {
+    CE_MARGIN_LOOP(DR, 1, i, lx, ly) {
+        if (IN || inside(lx, ly)) {
             P[3][i] = pass3x3<DR, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
             P[4][i] = pass3x3<DR, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
     // S2: chroma pre-blur pass 2 (margin 2): P3,P4 -> P1,P2 (their old contents are dead) ; img = (P0, P1, P2)
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 2 && lx < DR - 2 && ly >= 2 && ly < DR - 2 && (IN || inside(lx, ly))) {
+    CE_MARGIN_LOOP(DR, 2, i, lx, ly) {
+        if (IN || inside(lx, ly)) {
             P[1][i] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
             P[2][i] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
     // S3a: first pass of mu (margin 3): img -> P3,P4,P5
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 3 && lx < DR - 3 && ly >= 3 && ly < DR - 3 && (IN || inside(lx, ly))) {
+    CE_MARGIN_LOOP(DR, 3, i, lx, ly) {
+        if (IN || inside(lx, ly)) {
             P[3][i] = pass3x3<DR, false, IN>(P[0], lx, ly, gx0, gy0, w, h);
             P[4][i] = pass3x3<DR, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
             P[5][i] = pass3x3<DR, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
@@ -153,9 +158,8 @@ __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], floa
     }
     __syncthreads();
     // S3b: first pass of sq = blur(img * img): img -> P3,P4,P5
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        if (lx >= 3 && lx < DR - 3 && ly >= 3 && ly < DR - 3 && (IN || inside(lx, ly))) {
+    CE_MARGIN_LOOP(DR, 3, i, lx, ly) {
+        if (IN || inside(lx, ly)) {
             P[3][i] = pass3x3<DR, true, IN>(P[0], lx, ly, gx0, gy0, w, h);
             P[4][i] = pass3x3<DR, true, IN>(P[1], lx, ly, gx0, gy0, w, h);
             P[5][i] = pass3x3<DR, true, IN>(P[2], lx, ly, gx0, gy0, w, h);
@@ -199,12 +203,13 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
     __syncthreads();
     auto load_rgb = [&](int X, int Y, float &r, float &gg, float &b) {
         if (FROM_U8) {
-            const uint8_t *px = src8 + ((size_t)Y * w + X) * 3;
+            // 32-bit: DSSIM keeps > 300 B per pixel resident, so an image that fits the device is far below 2^32 / 3 pixels
+            const uint8_t *px = src8 + ((uint32_t)Y * (uint32_t)w + (uint32_t)X) * 3u;
             r = s_lut[px[0]];
             gg = s_lut[px[1]];
             b = s_lut[px[2]];
         } else {
-            const size_t o = (size_t)Y * g.pitch + X;
+            const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
             r = srcf[o];
             gg = srcf[o + g.plane];
             b = srcf[o + 2 * g.plane];
@@ -271,9 +276,8 @@ __device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], f
                                                        float *__restrict__ map, const lvl_geom &g, uint32_t p, int x0, int y0)
 {
     const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 2, gy0 = y0 - 2;
-    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
-        const int lx = i % CR, ly = i / CR;
-        if (lx >= 1 && lx < CR - 1 && ly >= 1 && ly < CR - 1 && (IN || (gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h))) {
+    CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
+        if (IN || (gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h)) {
 #pragma unroll
             for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, false, IN>(M[c], lx, ly, gx0, gy0, w, h);
         }
