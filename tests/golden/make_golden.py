@@ -29,6 +29,11 @@ CASES = [  # name, w, h, seed, kind, quality, 4:2:0
     ("flat40x56_q90", 40, 56, 15, "flat", 90, False),
     ("nat192x128_q95", 192, 128, 16, "natural", 95, False),
     ("nat192x128_q20", 192, 128, 16, "natural", 20, False),
+    # edge shapes: the smallest image every metric accepts, one-tile-high strips, sizes off every tile / pyramid multiple
+    ("min8x8_q50", 8, 8, 17, "natural", 50, False),
+    ("wide301x9_q70", 301, 9, 18, "natural", 70, False),
+    ("tall9x301_q70", 9, 301, 19, "natural", 70, False),
+    ("odd257x129_q30_420", 257, 129, 20, "natural", 30, True),
 ]
 
 

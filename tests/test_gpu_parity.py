@@ -436,3 +436,37 @@ def test_helpers_mirror_dssim(gpu_ctx, ce):
         ce.assert_perception_level(gpu_ctx, img, shifted, "Imperceptible")
     with pytest.raises(ce.QualityBelowThreshold):
         ce.assert_quality(gpu_ctx, img, shifted, None, 0.0001)
+
+
+# ---------------------------------------------------------- committed golden vectors ----------
+
+
+def test_committed_golden_vectors_through_the_c_abi(gpu_ctx, ce):
+    """tests/golden/{inputs.npz, scores.json} (made by tests/golden/make_golden.py with the oracle, committed): the HIP
+    path against the FILES, with no oracle in the loop - integer / byte results exact, the three perceptual scores
+    within the parity bar (they are in fact much closer: the device planes are bit-identical to the oracle's)."""
+    import hashlib
+    import json
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "scores.json")) as f:
+        scores = json.load(f)
+    arrays = np.load(os.path.join(here, "golden", "inputs.npz"))
+    assert len(scores) >= 8
+    worst = {"ssimulacra2": 0.0, "dssim": 0.0, "butteraugli": 0.0}
+    for name, s in scores.items():
+        ref, test, w, h = arrays[name + ".ref"], arrays[name + ".test"], s["width"], s["height"]
+        assert gpu_ctx.calculate_psnr(ref, test, w, h) == s["psnr"], name
+        rt = gpu_ctx.xyb_roundtrip(ref, w, h)
+        assert hashlib.sha256(np.asarray(rt).tobytes()).hexdigest() == s["xyb_roundtrip_sha256"], name
+        m = gpu_ctx.calculate_metrics(ref, test, w, h, ce.MetricConfig.all())
+        assert m.psnr == s["psnr"], name
+        for key, got, floor in (("ssimulacra2", m.ssimulacra2, 1.0), ("dssim", m.dssim, 1e-3), ("butteraugli", m.butteraugli, 1.0)):
+            assert rel_close(got, s[key], floor=floor), (name, key, got, s[key])
+            worst[key] = max(worst[key], abs(got - s[key]) / max(abs(s[key]), floor))
+        # the XYB-roundtripped reference (session.rs:447-456) against its own golden values
+        mx = gpu_ctx.calculate_metrics(ref, test, w, h, ce.MetricConfig.all().with_xyb_roundtrip())
+        assert mx.psnr == s["psnr_xyb_ref"], name
+        assert rel_close(mx.ssimulacra2, s["ssimulacra2_xyb_ref"]), name
+    assert worst["ssimulacra2"] < 1e-6 and worst["dssim"] < 1e-6 and worst["butteraugli"] < 1e-6, worst
