@@ -241,6 +241,18 @@ int ce_ctx_synchronize(ce_ctx *ctx)
 
 void *ce_ctx_stream(ce_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// batches launched and not yet collected, per device, over all contexts of the process: ce_batch_launch forks a larger
+// batch's metric chains only when nothing else is in flight beside it
+static std::atomic<int> g_in_flight[64];
+static std::atomic<int> &in_flight_of(const ce_ctx *ctx) { return g_in_flight[(unsigned)ctx->device % 64u]; }
+static void leave_flight(ce_batch *b)
+{
+    if (b->counted_in_flight) {
+        in_flight_of(b->ctx).fetch_sub(1, std::memory_order_relaxed);
+        b->counted_in_flight = false;
+    }
+}
+
 const char *ce_last_error(const ce_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err_noctx.c_str(); }
 
 // ---- resident batch ------------------------------------------------------------------------
@@ -298,6 +310,7 @@ void ce_batch_destroy(ce_batch *b)
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
+    leave_flight(b);
     if (b->up_stream) hipStreamSynchronize(b->up_stream), hipStreamDestroy(b->up_stream);
     if (b->h_wide) hipHostFree(b->h_wide);
     hipFree(b->d_wide);
@@ -674,24 +687,42 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     const bool run_ssim2 = (metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8;
     const bool run_dssim = (metric_mask & CE_METRIC_DSSIM) != 0;
     const bool run_ba = (metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8;
-    // Measured (profiles/README.md, round 2): on the Kodak grid the forked chains take 8.7 ms per step, the same chains
-    // back to back 7.3 ms (6.8 with two steps in flight) - side by side they evict each other's reference planes from
-    // L2 and halve each other's resident workgroups.  So the default keeps the chains back to back on the context's
-    // stream (SSIMULACRA2 still overlaps its level-0 passes with its tail levels); CE_METRIC_STREAMS=fork restores the
-    // forked schedule for A/B runs.
+    // Side by side or back to back?  Measured (profiles/r02_experiments.md sections 1, 12, 15): a SMALL batch is bound by
+    // the latency of its ~130 dependent launches, and three chains side by side hide each other's gaps (one Kodak pair
+    // 0.76 -> 0.54 ms, eight 1.37 -> 1.23 ms, one 4K pair 3.65 -> 2.94 ms); a LARGE grid fills the GPU from one chain,
+    // and with other batches in flight beside it (two shape buckets, two steps) forked chains evict each other's
+    // reference planes from L2 and halve each other's resident workgroups (Kodak grid 6.55 -> 7.55 ms per step).  So the
+    // chains fork when the batch holds at most CE_METRIC_FORK_BELOW_MP megapixels of pairs (default 4), or at most
+    // CE_METRIC_FORK_ALONE_BELOW_MP (default 64) while no other batch of this device is launched and uncollected, and run
+    // back to back on the context's stream otherwise (SSIMULACRA2 still overlaps its level-0 passes with its tail
+    // levels).  Scores do not depend on the schedule.
     // fork mask: bit k = metric chain k (0 SSIMULACRA2, 1 DSSIM, 2 Butteraugli) runs on its own stream beside the others.
-    // CE_METRIC_STREAMS = "fork" (all three), "fork:dssim", "fork:ssim2,ba", ... ; unset / "serial" = none.
-    static const unsigned fork_mask_env = [] {
+    // CE_METRIC_STREAMS = "fork" (all three, always), "fork:dssim", "fork:ssim2,ba", ... (those, always), "serial" (never);
+    // unset / "auto" = by size.
+    static const int fork_mask_env = [] {
         const char *e = std::getenv("CE_METRIC_STREAMS");
-        if (!e || std::strncmp(e, "fork", 4) != 0) return 0u;
-        if (e[4] != ':') return 7u;
-        unsigned m = 0;
-        if (std::strstr(e + 5, "ssim2")) m |= 1u;
-        if (std::strstr(e + 5, "dssim")) m |= 2u;
-        if (std::strstr(e + 5, "ba")) m |= 4u;
+        if (!e || std::strcmp(e, "auto") == 0) return -1;
+        if (std::strncmp(e, "fork", 4) != 0) return 0;
+        if (e[4] != ':') return 7;
+        int m = 0;
+        if (std::strstr(e + 5, "ssim2")) m |= 1;
+        if (std::strstr(e + 5, "dssim")) m |= 2;
+        if (std::strstr(e + 5, "ba")) m |= 4;
         return m;
     }();
-    const unsigned fork_mask = (!ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1) ? fork_mask_env : 0u;
+    static const double fork_below_mp = [] {
+        const char *e = std::getenv("CE_METRIC_FORK_BELOW_MP");
+        return e ? std::atof(e) : CE_DEFAULT_FORK_BELOW_MP;
+    }();
+    static const double fork_alone_below_mp = [] {
+        const char *e = std::getenv("CE_METRIC_FORK_ALONE_BELOW_MP");
+        return e ? std::atof(e) : CE_DEFAULT_FORK_ALONE_BELOW_MP;
+    }();
+    const double batch_mp = (double)n_pairs * b->w * b->h * 1e-6;
+    const int others = in_flight_of(ctx).load(std::memory_order_relaxed) - (b->counted_in_flight ? 1 : 0);
+    const bool by_size = batch_mp <= fork_below_mp || (others <= 0 && batch_mp <= fork_alone_below_mp);
+    const unsigned fork_wanted = fork_mask_env >= 0 ? (unsigned)fork_mask_env : (by_size ? 7u : 0u);
+    const unsigned fork_mask = (!ctx->prof_serial && (int)run_ssim2 + (int)run_dssim + (int)run_ba > 1) ? fork_wanted : 0u;
     hipStream_t base = ctx->stream;
     if (fork_mask) {
         if (!b->ev_fork) CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
@@ -731,6 +762,10 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     b->last_mask = metric_mask;
     CE_HIP(ctx, hipEventRecord(b->ev_run, ctx->stream));
     b->run_pending = true;
+    if (!b->counted_in_flight) {
+        in_flight_of(ctx).fetch_add(1, std::memory_order_relaxed);
+        b->counted_in_flight = true;
+    }
     return CE_OK;
 }
 
@@ -744,6 +779,7 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
                                ctx->stream));
     CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     b->run_pending = false;
+    leave_flight(b);
     const uint32_t mask = b->last_mask;
     for (uint32_t i = 0; i < n_pairs; i++) {
         ce_scores s{};

@@ -40,6 +40,15 @@ struct ce_kernel_stat {
     double total_ms = 0.0;
 };
 
+// metric chains of a batch run side by side when the batch holds at most this many megapixels of pairs (ce_api.cpp,
+// ce_batch_launch; measured in profiles/r02_experiments.md section 15); CE_METRIC_FORK_BELOW_MP overrides it
+#ifndef CE_DEFAULT_FORK_BELOW_MP
+#define CE_DEFAULT_FORK_BELOW_MP 4.0
+#endif
+#ifndef CE_DEFAULT_FORK_ALONE_BELOW_MP
+#define CE_DEFAULT_FORK_ALONE_BELOW_MP 64.0
+#endif
+
 struct ce_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -99,6 +108,7 @@ struct ce_batch {
     hipStream_t up_stream = nullptr;
     hipEvent_t ev_up = nullptr, ev_run = nullptr;  // uploads done / last launch done
     bool uploads_pending = false, run_pending = false;
+    bool counted_in_flight = false;  // this batch is in the device's launched-and-not-collected count (ce_api.cpp: g_in_flight)
     // wide ingest (RGBA8 / 16-bit sources): one pinned + one device staging image of 8 B/px, made on first use
     uint8_t *h_wide = nullptr, *d_wide = nullptr;
 
