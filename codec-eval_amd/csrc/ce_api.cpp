@@ -845,8 +845,8 @@ size_t ce_estimate_batch_bytes(uint32_t w, uint32_t h, uint32_t n_refs, uint32_t
         bytes += px * (20.0 * slots + 80.0 * pairs);
         allocations += 24;
     }
-    if (metric_mask & CE_METRIC_DSSIM) {  // linear ping-pong 6, img / mu / sq 36 per slot, the references' per-level planes 48; SSIM map 4 per pair
-        bytes += px * (42.0 * slots + 48.0 * n_refs + 4.0 * pairs);
+    if (metric_mask & CE_METRIC_DSSIM) {  // linear ping-pong 6 per slot; img 12 + SSIM map 4 per pair; the references' per-level img / mu / sq 48
+        bytes += px * (6.0 * slots + 48.0 * n_refs + 16.0 * pairs);
         allocations += 24;
     }
     if (metric_mask & CE_METRIC_BUTTERAUGLI) {  // half-res linear 3, PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; diffmaps 5 + ac / dc 24 per pair

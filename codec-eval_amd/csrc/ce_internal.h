@@ -154,14 +154,10 @@ struct ce_batch {
     int ds_levels = 0;
     dssim_level ds[CE_DSSIM_SCALES];
     float *ds_lin[2] = {};     // linear RGB of the current and the next level
-    float *ds_img = nullptr;   // L, a', b' (chroma pre-blurred)
-    float *ds_mu = nullptr;    // blur(img)
-    float *ds_sq = nullptr;    // blur(img*img)
+    float *ds_img = nullptr;   // [max_pairs][3][plane_0]: L, a', b' (chroma pre-blurred) of the distorted images, one level at a time
     float *ds_rimg[CE_DSSIM_SCALES] = {}, *ds_rmu[CE_DSSIM_SCALES] = {}, *ds_rsq[CE_DSSIM_SCALES] = {};  // the references' planes, per level: [max_refs][3][plane_l]
     const uint8_t *ds_ref_src = nullptr;  // reference slab those planes were built from (valid while keep_ref_pyramid)
     uint32_t ds_ref_count = 0;
-    float *ds_tmp[2] = {};     // blur pass scratch
-    float *ds_i12 = nullptr;   // [pairs][3][plane] blur(img1*img2)
     float *ds_map = nullptr;   // [pairs][plane] SSIM map
     double *ds_part = nullptr; // [pairs][levels][2][blocks] partial sums (sum, abs-dev)
     double *ds_level_scores = nullptr;  // [pairs][levels]

@@ -3,9 +3,14 @@
 //
 // Per level (5 levels, each the 2x2 average of the previous in LINEAR RGB, floor sizes):
 //   per image slot ("create_image", references once per reference, not once per pair):
-//     linear RGB -> normalised L*a*b*  ->  chroma planes pre-blurred  ->  mu = blur(img), sq = blur(img*img)
+//     linear RGB -> normalised L*a*b*  ->  chroma planes pre-blurred (= img);  references also: mu = blur(img),
+//     sq = blur(img*img), kept per level for all their pairs (and across launches for a reference handle)
 //   per pair ("compare"):
-//     i12 = blur(img1*img2) -> SSIM map over the channel-averaged statistics -> mean -> mean |avg - ssim|
+//     the distorted image's mu / sq and i12 = blur(img1*img2) from the one img tile the kernel loads anyway ->
+//     SSIM map over the channel-averaged statistics -> mean -> mean |avg - ssim|
+//   (a distorted image's mu / sq are used by exactly one compare: computing them there instead of in create_image
+//   saves their round trip through HBM - 48 B per pixel and level - and moves their arithmetic from the VALU-bound
+//   create kernels into the compare kernel, which waits on memory)
 // "blur" is the fixed 3x3 kernel applied twice with edge replication.  Every plane op keeps the
 // oracle's f32 operation order (oracle/dssim.c), so planes are bit-identical; sums are f64.
 // Build with -ffp-contract=off.
@@ -100,16 +105,17 @@ struct lvl_geom {
 // Writes img, mu, sq (9 planes) for the tile; every intermediate lives in LDS only.
 constexpr int DT = 32, DR = DT + 8;
 
-// the elements of an R x R LDS region that lie at least M away from its border, TPB at a time: j runs over the compact
-// (R - 2M)^2 index space, so no lane of any iteration but the last is masked off (looping over all R * R elements with a
-// margin test leaves a third of the issue slots of the margin-3 stages empty, and the create kernels are VALU-bound)
+// The elements of an R x R LDS region that lie at least M away from its border, TPB at a time.  The loop runs over ALL
+// R * R elements with a margin test, so consecutive lanes always touch consecutive LDS words: looping over the compact
+// (R - 2M)^2 index space instead saves a tenth of the wave-instructions but makes every second half-wave straddle two
+// region rows (R - 2M = 34 lanes of one, then the next), a two-way bank conflict on every access - measured in round 2:
+// SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS 0.00 -> 1.0 (compare), -> 1.8 (create), no time gained.
 #define CE_MARGIN_LOOP(R, M, i, lx, ly)                                                                               \
-    for (int j_ = threadIdx.x, lx = j_ % ((R) - 2 * (M)) + (M), ly = j_ / ((R) - 2 * (M)) + (M), i = ly * (R) + lx;    \
-         j_ < ((R) - 2 * (M)) * ((R) - 2 * (M));                                                                       \
-         j_ += TPB, lx = j_ % ((R) - 2 * (M)) + (M), ly = j_ / ((R) - 2 * (M)) + (M), i = ly * (R) + lx)
+    _Pragma("unroll 1") for (int i = threadIdx.x, lx = i % (R), ly = i / (R); i < (R) * (R); i += TPB, lx = i % (R), ly = i / (R)) \
+        if (lx >= (M) && lx < (R) - (M) && ly >= (M) && ly < (R) - (M))
 
-// stages S1..S4 of k_dssim_create on the LDS planes; IN = the block's whole 40x40 region is inside the image
-template <bool IN>
+// FULL = a reference slot (img, mu, sq); otherwise a distorted image (img only: S1, S2 and the img store)
+template <bool IN, bool FULL>
 __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], float *__restrict__ img, float *__restrict__ mu,
                                                     float *__restrict__ sq, const lvl_geom &g, uint32_t slot, int x0, int y0)
 {
@@ -133,6 +139,19 @@ __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], floa
         }
     }
     __syncthreads();
+    if (!FULL) {  // a distorted image: img is all that leaves (its mu / sq are formed by the compare kernel)
+        for (int i = threadIdx.x; i < DT * DT; i += TPB) {
+            const int tx = i % DT, ty = i / DT, X = x0 + tx, Y = y0 + ty;
+            if (IN || (X < w && Y < h)) {
+                const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
+                const int li = (ty + 4) * DR + tx + 4;
+                img[o] = P[0][li];
+                img[o + g.plane] = P[1][li];
+                img[o + 2 * g.plane] = P[2][li];
+            }
+        }
+        return;
+    }
     // S3a: first pass of mu (margin 3): img -> P3,P4,P5
     CE_MARGIN_LOOP(DR, 3, i, lx, ly) {
         if (IN || inside(lx, ly)) {
@@ -181,8 +200,8 @@ __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], floa
 template <bool FROM_U8>
 __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
                                                       const float *__restrict__ lut, const float *__restrict__ lin_in,
-                                                      float *__restrict__ lin_out, float *__restrict__ img, float *__restrict__ mu,
-                                                      float *__restrict__ sq, float *__restrict__ rimg, float *__restrict__ rmu,
+                                                      float *__restrict__ lin_out, float *__restrict__ img,
+                                                      float *__restrict__ rimg, float *__restrict__ rmu,
                                                       float *__restrict__ rsq, lvl_geom g, lvl_geom gn, int has_next,
                                                       size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
 {
@@ -192,9 +211,9 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
     // z0 > 0: the references' planes of this level are cached (reference handle), only the distorted slots are built
     const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);
     // a reference's img / mu / sq go to its own per-level buffers (slot z there) so that they survive the level loop
-    // and the next launches; a distorted image's go to the shared per-launch buffers (slot max_refs + pair)
+    // and the next launches; a distorted image's img goes to the shared per-launch buffer (slot = pair index)
     const bool is_ref = z < n_refs_used;
-    float *oimg = is_ref ? rimg : img, *omu = is_ref ? rmu : mu, *osq = is_ref ? rsq : sq;
+    const uint32_t oslot = is_ref ? z : z - n_refs_used;
     const int w = (int)g.w, h = (int)g.h;
     const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 4, gy0 = y0 - 4;
     const uint8_t *src8 = nullptr;
@@ -238,10 +257,18 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
     __syncthreads();
     // S1..S4 (two chroma pre-blur passes, two passes each for mu and sq, stores): a block whose 40x40 region is
     // wholly inside the image takes the variant without clamping or bounds tests
-    if (gx0 >= 0 && gy0 >= 0 && gx0 + DR <= w && gy0 + DR <= h)
-        dssim_create_stages<true>(P, oimg, omu, osq, g, slot, x0, y0);
-    else
-        dssim_create_stages<false>(P, oimg, omu, osq, g, slot, x0, y0);
+    const bool in = gx0 >= 0 && gy0 >= 0 && gx0 + DR <= w && gy0 + DR <= h;
+    if (is_ref) {
+        if (in)
+            dssim_create_stages<true, true>(P, rimg, rmu, rsq, g, oslot, x0, y0);
+        else
+            dssim_create_stages<false, true>(P, rimg, rmu, rsq, g, oslot, x0, y0);
+    } else {
+        if (in)
+            dssim_create_stages<true, false>(P, img, nullptr, nullptr, g, oslot, x0, y0);
+        else
+            dssim_create_stages<false, false>(P, img, nullptr, nullptr, g, oslot, x0, y0);
+    }
 }
 
 __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -265,64 +292,138 @@ constexpr int CR = DT + 4;
 // form on the Kodak grid - the per-block loop with two barriers per distorted image costs more latency than the
 // reference re-reads cost bandwidth; with 24 x 16 tiles per image the blocks of consecutive pairs of a reference
 // already land on the same XCD, 384 = 0 mod 8.)
-// the blur of img1*img2 (second pass) and compare_scale on the LDS planes; IN = the block's 36x36 region is inside the image
+// The distorted image's mu = blur(img2) and sq = blur(img2 * img2), and i12 = blur(img1 * img2): three two-pass 3x3 blurs
+// of the SAME 36x36 region (tile + halo 2), each the same pass3x3 sequence create_image runs for a reference (same taps,
+// same order, same edge replication: bit-identical to Dssim::create_image of the distorted image).  LDS planes: A = img2,
+// M = img1 * img2, T = first-pass output; M is reused as first-pass output once its own first pass is done:
+//   P1  T = pass(M)                       | barrier
+//   P2  s12 = pass(T);  M = pass(A)       | barrier
+//   P3  mu2 = pass(M);  T = pass(A^2)     | barrier
+//   P4  sq2 = pass(T);  SSIM
+// IN = the block's whole 36x36 region is inside the image (no clamping, no bounds tests).
 constexpr int CMP_OUT = DT * DT / TPB;  // output pixels per thread (4)
+// Left alone, the compiler reads the 27 taps of each of a thread's four pixels in P2 / P3 and SINKS the sums to their use
+// in P4, keeping (spilling) the raw taps instead of the 12 results: 290 registers, or 500 B of scratch under a cap.
+// CE_KEEP pins a result in a register where it is computed; the memory fence keeps one pixel's taps live at a time.
+#define CE_SCHED_FENCE() asm volatile("" ::: "memory")
+#define CE_KEEP(x) asm volatile("" : "+v"(x))
 struct cmp_stats {
-    float u1[CMP_OUT][3], u2[CMP_OUT][3], q1[CMP_OUT][3], q2[CMP_OUT][3];  // mu and blur(img^2) of both images at this thread's pixels
+    float u1[CMP_OUT][3], q1[CMP_OUT][3];  // mu and blur(img^2) of the REFERENCE at this thread's pixels
 };
 
 template <bool IN>
-__device__ __forceinline__ double dssim_compare_stages(float (&M)[3][CR * CR], float (&T)[3][CR * CR], const cmp_stats &st,
-                                                       float *__restrict__ map, const lvl_geom &g, uint32_t p, int x0, int y0)
+__device__ __forceinline__ double dssim_compare_stages(float (&A)[3][CR * CR], float (&M)[3][CR * CR], float (&T)[3][CR * CR],
+                                                       const float *__restrict__ r_mu, const float *__restrict__ r_sq,
+                                                       float *__restrict__ map, const lvl_geom &g, int x0, int y0)
 {
     const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 2, gy0 = y0 - 2;
+    const uint32_t plane = (uint32_t)g.plane;
+    auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
+    float s12[CMP_OUT][3], u2[CMP_OUT][3], q2[CMP_OUT][3];
+    // P1
     CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
-        if (IN || (gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h)) {
+        if (IN || inside(lx, ly)) {
 #pragma unroll
             for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, false, IN>(M[c], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
+    // P2
+#pragma unroll
+    for (int k = 0; k < CMP_OUT; k++) {
+        const int i = k * TPB + (int)threadIdx.x, tx = i % DT, ty = i / DT;
+        if (IN || (x0 + tx < w && y0 + ty < h)) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                s12[k][c] = pass3x3<CR, false, IN>(T[c], tx + 2, ty + 2, gx0, gy0, w, h);
+                CE_KEEP(s12[k][c]);
+            }
+        }
+        CE_SCHED_FENCE();
+    }
+    CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
+        if (IN || inside(lx, ly)) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) M[c][i] = pass3x3<CR, false, IN>(A[c], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // P3
+#pragma unroll
+    for (int k = 0; k < CMP_OUT; k++) {
+        const int i = k * TPB + (int)threadIdx.x, tx = i % DT, ty = i / DT;
+        if (IN || (x0 + tx < w && y0 + ty < h)) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                u2[k][c] = pass3x3<CR, false, IN>(M[c], tx + 2, ty + 2, gx0, gy0, w, h);
+                CE_KEEP(u2[k][c]);
+            }
+        }
+        CE_SCHED_FENCE();
+    }
+    // the reference's mu / blur(img^2) at this thread's pixels: requested here, consumed in P4 behind the last first pass
+    // (pixels outside the image are clamped, never used)
+    cmp_stats st;
+#pragma unroll
+    for (int k = 0; k < CMP_OUT; k++) {
+        const int i = k * TPB + (int)threadIdx.x;
+        const int X = min(x0 + i % DT, w - 1), Y = min(y0 + i / DT, h - 1);
+        const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            st.u1[k][c] = r_mu[c * plane + o];
+            st.q1[k][c] = r_sq[c * plane + o];
+        }
+    }
+    CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
+        if (IN || inside(lx, ly)) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, true, IN>(A[c], lx, ly, gx0, gy0, w, h);
+        }
+    }
+    __syncthreads();
+    // P4
     double val = 0.0;
 #pragma unroll
     for (int k = 0; k < CMP_OUT; k++) {
         const int i = k * TPB + (int)threadIdx.x;
         const int tx = i % DT, ty = i / DT, lx = tx + 2, ly = ty + 2, X = x0 + tx, Y = y0 + ty;
         if (IN || (X < w && Y < h)) {
-            const size_t o = (size_t)Y * g.pitch + X;
+            const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
             const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
-            float m11[3], m12[3], m22[3], s1[3], s2[3], s12[3];
+            float m11[3], m12[3], m22[3], s1[3], s2[3], s12c[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float u1 = st.u1[k][c], u2 = st.u2[k][c];
+                q2[k][c] = pass3x3<CR, false, IN>(T[c], lx, ly, gx0, gy0, w, h);
+                const float u1 = st.u1[k][c], u2v = u2[k][c];
                 m11[c] = u1 * u1;
-                m12[c] = u1 * u2;
-                m22[c] = u2 * u2;
+                m12[c] = u1 * u2v;
+                m22[c] = u2v * u2v;
                 s1[c] = st.q1[k][c] - m11[c];
-                s2[c] = st.q2[k][c] - m22[c];
-                s12[c] = pass3x3<CR, false, IN>(T[c], lx, ly, gx0, gy0, w, h) - m12[c];
+                s2[c] = q2[k][c] - m22[c];
+                s12c[c] = s12[k][c] - m12[c];
             }
 #define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
             const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
-            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12);
+            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12c);
 #undef AVG3
             const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
-            map[(size_t)p * g.plane + o] = ssim;
+            map[o] = ssim;
             val += (double)ssim;
         }
+        CE_SCHED_FENCE();
     }
     return val;
 }
 
-__global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ mu,
-                                                       const float *__restrict__ sq, const float *__restrict__ rimg,
+__global__ __launch_bounds__(TPB, 3) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ rimg,
                                                        const float *__restrict__ rmu, const float *__restrict__ rsq,
                                                        const uint32_t *__restrict__ pair_ref,
                                                        float *__restrict__ map, double *__restrict__ part, lvl_geom g,
-                                                       uint32_t max_refs, uint32_t level, uint32_t n_levels, uint32_t n_blocks,
+                                                       uint32_t level, uint32_t n_levels, uint32_t n_blocks,
                                                        const uint2 *__restrict__ work, uint32_t tiles_x)
 {
-    __shared__ float M[3][CR * CR], T[3][CR * CR];
+    __shared__ float A[3][CR * CR], M[3][CR * CR], T[3][CR * CR];
     __shared__ double s_red[TPB / 64];
     // XCD-aware 1-D launch (ce_build_xcd_list): the pairs of a reference run the same tile back to back on one XCD
     const uint2 wi = work[blockIdx.x];
@@ -330,35 +431,25 @@ __global__ __launch_bounds__(TPB) void k_dssim_compare(const float *__restrict__
     const uint32_t p = wi.y;
     const int w = (int)g.w, h = (int)g.h;
     const int x0 = (int)(wi.x % tiles_x) * DT, y0 = (int)(wi.x / tiles_x) * DT, gx0 = x0 - 2, gy0 = y0 - 2;
-    const size_t sa = (size_t)pair_ref[p] * 3 * g.plane, sb = (size_t)(max_refs + p) * 3 * g.plane;
-    // The kernel waits on memory, not on arithmetic (round-2 counters: VALU busy 0.34, 0.65 of the wave-cycles parked),
-    // in TWO rounds - the product tile, then mu / blur(img^2) behind two barriers.  The second round is requested here,
-    // before the first, so both are in flight together (48 registers; pixels outside the image are clamped, never used).
-    cmp_stats st;
-#pragma unroll
-    for (int k = 0; k < CMP_OUT; k++) {
-        const int i = k * TPB + (int)threadIdx.x;
-        const int X = min(x0 + i % DT, w - 1), Y = min(y0 + i / DT, h - 1);
-        const size_t o = (size_t)Y * g.pitch + X;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            st.u1[k][c] = rmu[sa + c * g.plane + o];
-            st.u2[k][c] = mu[sb + c * g.plane + o];
-            st.q1[k][c] = rsq[sa + c * g.plane + o];
-            st.q2[k][c] = sq[sb + c * g.plane + o];
-        }
-    }
+    // block-uniform bases (scalar registers); everything a thread adds to them fits 32 bits (three planes of ONE image)
+    const float *r_img = rimg + (size_t)pair_ref[p] * 3 * g.plane, *r_mu = rmu + (size_t)pair_ref[p] * 3 * g.plane,
+                *r_sq = rsq + (size_t)pair_ref[p] * 3 * g.plane, *t_img = img + (size_t)p * 3 * g.plane;
+    const uint32_t plane = (uint32_t)g.plane;
     for (int i = threadIdx.x; i < CR * CR; i += TPB) {
         const int lx = i % CR, ly = i / CR;
         const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
-        const size_t o = (size_t)Y * g.pitch + X;
+        const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
 #pragma unroll
-        for (int c = 0; c < 3; c++) M[c][i] = rimg[sa + c * g.plane + o] * img[sb + c * g.plane + o];
+        for (int c = 0; c < 3; c++) {
+            const float t = t_img[c * plane + o];
+            A[c][i] = t;
+            M[c][i] = r_img[c * plane + o] * t;
+        }
     }
     __syncthreads();
     const double val = (gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h)
-                           ? dssim_compare_stages<true>(M, T, st, map, g, p, x0, y0)
-                           : dssim_compare_stages<false>(M, T, st, map, g, p, x0, y0);
+                           ? dssim_compare_stages<true>(A, M, T, r_mu, r_sq, map + (size_t)p * g.plane, g, x0, y0)
+                           : dssim_compare_stages<false>(A, M, T, r_mu, r_sq, map + (size_t)p * g.plane, g, x0, y0);
     const double t = block_sum(val, s_red);
     if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + wi.x] = t;
 }
@@ -445,8 +536,7 @@ __global__ __launch_bounds__(64) void k_dssim_finalize_pairs(const double *__res
 void ce_dssim_free(ce_batch *b)
 {
     for (auto &p : b->ds_lin) hipFree(p), p = nullptr;
-    for (auto &p : b->ds_tmp) hipFree(p), p = nullptr;
-    hipFree(b->ds_img); hipFree(b->ds_mu); hipFree(b->ds_sq); hipFree(b->ds_i12); hipFree(b->ds_map);
+    hipFree(b->ds_img); hipFree(b->ds_map);
     for (int l = 0; l < CE_DSSIM_SCALES; l++) {
         hipFree(b->ds_rimg[l]); hipFree(b->ds_rmu[l]); hipFree(b->ds_rsq[l]);
         b->ds_rimg[l] = b->ds_rmu[l] = b->ds_rsq[l] = nullptr;
@@ -454,7 +544,7 @@ void ce_dssim_free(ce_batch *b)
     }
     b->ds_ref_src = nullptr;
     hipFree(b->ds_part); hipFree(b->ds_level_scores);
-    b->ds_img = b->ds_mu = b->ds_sq = b->ds_i12 = b->ds_map = nullptr;
+    b->ds_img = b->ds_map = nullptr;
     b->ds_part = b->ds_level_scores = nullptr;
     b->dssim_ready = false;
 }
@@ -483,9 +573,7 @@ static int dssim_allocate(ce_batch *b)
     const size_t p1 = n > 1 ? b->ds[1].plane : 1;
     CE_HIP(ctx, hipMalloc(&b->ds_lin[0], slots * 3 * p1 * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ds_lin[1], slots * 3 * p1 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_img, slots * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_mu, slots * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ds_sq, slots * 3 * p0 * sizeof(float)));
+    CE_HIP(ctx, hipMalloc(&b->ds_img, (size_t)b->max_pairs * 3 * p0 * sizeof(float)));  // the distorted images' img, one level at a time
     // the references' planes, one set per level: they outlive the level loop (Dssim::create_image of the reference is
     // run once per reference, dssim.rs:54-59; a reference handle keeps them across compares)
     for (int l = 0; l < n; l++) {
@@ -536,17 +624,17 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         // create_image for every used slot (references once per reference)
         if (l == 0)
             CE_LAUNCH(ctx, "dssim_create_u8", k_dssim_create<true>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
-                      ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_mu, b->ds_sq, b->ds_rimg[l], b->ds_rmu[l],
+                      ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_rimg[l], b->ds_rmu[l],
                       b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         else
             CE_LAUNCH(ctx, "dssim_create", k_dssim_create<false>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
-                      ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img, b->ds_mu, b->ds_sq,
+                      ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img,
                       b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         // compare per pair
         if ((rc = ce_build_xcd_list(b, n_pairs, tiles.x * tiles.y, &b->ds_work[l])) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, b->ds_img, b->ds_mu, b->ds_sq,
+        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, (const float *)b->ds_img,
                   (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
-                  b->ds_part, lg, mr, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
+                  b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
                   (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
         const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);

@@ -96,11 +96,13 @@ def dssim_bytes(b: Bucket, acc: Dict[str, float]):
     for l, (w, h) in enumerate(lv):
         n = w * h
         nn = lv[l + 1][0] * lv[l + 1][1] if l + 1 < len(lv) else 0
-        # create_image: linear RGB in, img / mu / sq (9 planes) out, next level's linear RGB out; L*a*b*, the chroma
-        # pre-blur and the 3x3 blur pairs never leave LDS
-        _add(acc, "dssim_create_u8" if l == 0 else "dssim_create", slots * ((3 if l == 0 else 12) * n + 36 * n + 12 * nn))
-        # compare: nine planes of the distorted image per pair, nine of the reference per reference, the SSIM map out
-        _add(acc, "dssim_compare", n * (36 * b.n_pairs + 36 * b.n_refs + 4 * b.n_pairs))
+        # create_image: linear RGB in, next level's linear RGB out, and img (3 planes) of a distorted image / img, mu, sq
+        # (9 planes) of a reference; L*a*b*, the chroma pre-blur and the 3x3 blur pairs never leave LDS
+        _add(acc, "dssim_create_u8" if l == 0 else "dssim_create",
+             slots * ((3 if l == 0 else 12) * n + 12 * nn) + 12 * n * b.n_pairs + 36 * n * b.n_refs)
+        # compare: img of the distorted image per pair (its mu / sq are formed in the kernel), nine planes of the
+        # reference per reference, the SSIM map out
+        _add(acc, "dssim_compare", n * (12 * b.n_pairs + 36 * b.n_refs + 4 * b.n_pairs))
         _add(acc, "dssim_absdev", n * 4 * b.n_pairs)
 
 
