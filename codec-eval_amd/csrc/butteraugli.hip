@@ -734,9 +734,9 @@ __device__ __forceinline__ void malta_rows_xy(const ba_f2 *__restrict__ base, ba
 //   <64, 512>: 72 x 72 tile (1.27x halo: 10 % fewer pre-scalings), 73 KB LDS, two blocks of eight waves per CU
 template <int MR, int NT>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
-                                                           float *__restrict__ ac, float *__restrict__ dc, geom g, uint32_t max_refs,
-                                                           uint32_t n_pairs_stride, malta_bands mb, const uint2 *__restrict__ work,
-                                                           uint32_t tiles_x)
+                                                           const float *__restrict__ blurred, const float *__restrict__ mask_vals,
+                                                           float *__restrict__ diffmap, geom g, uint32_t max_refs,
+                                                           malta_bands mb, const uint2 *__restrict__ work, uint32_t tiles_x)
 {
     constexpr int MLR = MR + 2 * MH, RSTEP = NT / 32;  // tile rows; output rows per step of the whole block
     __shared__ __attribute__((aligned(16))) ba_f2 s[MLR * ML];
@@ -808,6 +808,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
         if (x >= g.w || y >= g.h) continue;
         const size_t o = (size_t)y * g.pitch + x;
         const ba_f2 sums = s_acc[(RSTEP * sub + ty) * MT + 2 * tq + r];
+        float acv[3], dcv[3];
 #pragma unroll
         for (uint32_t c = 0; c < 3; c++) {
             float total = c == 0 ? sums.x : c == 1 ? sums.y : 0.0f;
@@ -827,12 +828,26 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
                 const float diff = a[(MF0 + c) * g.plane + o] - b[(MF0 + c) * g.plane + o];
                 total = __builtin_fmaf(diff * diff, wmul[3 + c], total);
             }
-            ac[((size_t)c * n_pairs_stride + p) * g.plane + o] = total;
+            acv[c] = total;
             {  // SetL2Diff on lf[c]
                 const float diff = a[(LF0 + c) * g.plane + o] - b[(LF0 + c) * g.plane + o];
-                dc[((size_t)c * n_pairs_stride + p) * g.plane + o] = (diff * diff) * wmul[6 + c];
+                dcv[c] = (diff * diff) * wmul[6 + c];
             }
         }
+        // CombineChannelsToDiffmap for this pixel (the mask values come from k_ba_mask_vals, once per reference): the
+        // block_diff_ac / block_diff_dc triples never leave registers
+        const size_t rslot = pair_ref[p];
+        const float maskval = mask_vals[(rslot * 2 + 0) * g.plane + o], dc_maskval = mask_vals[(rslot * 2 + 1) * g.plane + o];
+        const float mdiff = blurred[rslot * g.plane + o] - blurred[((size_t)max_refs + p) * g.plane + o];
+        float ac0 = acv[0], ac1 = acv[1], ac2 = acv[2];
+        float dc0 = dcv[0], dc1 = dcv[1], dc2 = dcv[2];
+        ac1 += 10.0f * mdiff * mdiff;  // kMaskToErrorMul
+        const float xmul = 1.0f;
+        ac0 *= xmul;
+        dc0 *= xmul;
+        const float mc_dc = dc0 * dc_maskval + dc1 * dc_maskval + dc2 * dc_maskval;
+        const float mc_ac = ac0 * maskval + ac1 * maskval + ac2 * maskval;
+        diffmap[(size_t)p * g.plane + o] = sqrtf(mc_dc + mc_ac);
     }
 }
 
@@ -873,14 +888,14 @@ __device__ __forceinline__ void store_min3(float v, float &min0, float &min1, fl
 }
 
 // mask = FuzzyErosion(blurred0); ac[1] += 10 (blurred0 - blurred1)^2; then CombineChannelsToDiffmap — one pass
-__global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict__ blurred, const uint32_t *__restrict__ pair_ref,
-                                                         const float *__restrict__ ac, const float *__restrict__ dc,
-                                                         float *__restrict__ diffmap, geom g, uint32_t n_pairs_stride, uint32_t max_refs)
+// MaskPsychoImage's per-pixel mask values depend on the REFERENCE's blurred mask input only (FuzzyErosion, then the two
+// f64 rational curves of MaskY / MaskDcY): formed once per reference slot - not once per pair - into two planes that a
+// reference handle keeps with the PsychoImage; the pair part of CombineChannelsToDiffmap is the Malta kernel's epilogue.
+__global__ __launch_bounds__(TPB) void k_ba_mask_vals(const float *__restrict__ blurred, float *__restrict__ vals, geom g)
 {
-    const uint32_t p = blockIdx.z;
+    const uint32_t z = blockIdx.z;  // reference slot
     BA_XY;
-    const float *from = blurred + (size_t)pair_ref[p] * g.plane;  // the reference's blurred mask input (per-slot planes)
-    const float *bl1 = blurred + (size_t)max_refs * g.plane;       // ... the distorted images' follow the references' 
+    const float *from = blurred + (size_t)z * g.plane;
     const int X = (int)x, Y = (int)y, W = (int)g.w, H = (int)g.h, S = 3;
     const uint32_t pitch = g.pitch;
 #define at(yy, xx) from[(size_t)(yy) * pitch + (xx)]
@@ -903,27 +918,15 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_combine(const float *__restrict
     store_min3(hu ? v_u : INF, min0, min1, min2);
     store_min3(hd ? v_d : INF, min0, min1, min2);
     const float mask = 0.45f * min0 + 0.3f * min1 + 0.25f * min2;
-    const float mdiff = c0 - bl1[(size_t)p * g.plane + o];
-
+#undef at
     const double kGlobalScale = 1.0 / (17.83 * 0.790799174);
     const double val = (double)mask;
     double c = 2.5485944793 / ((0.451936922203 * val) + 0.829591754942);
     double rv = kGlobalScale * (1.0 + c);
-    const float maskval = (float)(rv * rv);
+    vals[((size_t)z * 2 + 0) * g.plane + o] = (float)(rv * rv);  // maskval
     c = 0.505054525019 / ((3.87449418804 * val) + 0.20025578522);
     rv = kGlobalScale * (1.0 + c);
-    const float dc_maskval = (float)(rv * rv);
-#undef at
-    const size_t pl = g.plane, kp = (size_t)n_pairs_stride * pl, po = (size_t)p * pl + o;
-    float ac0 = ac[po], ac1 = ac[kp + po], ac2 = ac[2 * kp + po];
-    float dc0 = dc[po], dc1 = dc[kp + po], dc2 = dc[2 * kp + po];
-    ac1 += 10.0f * mdiff * mdiff;  // kMaskToErrorMul
-    const float xmul = 1.0f;
-    ac0 *= xmul;
-    dc0 *= xmul;
-    const float mc_dc = dc0 * dc_maskval + dc1 * dc_maskval + dc2 * dc_maskval;
-    const float mc_ac = ac0 * maskval + ac1 * maskval + ac2 * maskval;
-    diffmap[po] = sqrtf(mc_dc + mc_ac);
+    vals[((size_t)z * 2 + 1) * g.plane + o] = (float)(rv * rv);  // dc_maskval
 }
 
 constexpr int BF_ROWS = 32;  // rows per block of k_ba_final
@@ -1128,11 +1131,12 @@ void ce_butteraugli_free(ce_batch *b)
         hipFree(b->ba_psy[l]);
         hipFree(b->ba_diff[l]);
         hipFree(b->ba_mask[l]);
+        hipFree(b->ba_mask_vals[l]);
+        b->ba_mask_vals[l] = nullptr;
         ce_free_xcd_list(&b->ba_work[l]);
         b->ba_lin[l] = b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
     }
     for (auto &p : b->ba_s) hipFree(p), p = nullptr;
-    for (auto &p : b->ba_pp) hipFree(p), p = nullptr;
     hipFree(b->ba_blk_max);
     hipFree(b->ba_blk_sums);
     hipFree(b->ba_pnorm);
@@ -1162,11 +1166,12 @@ static int ba_allocate(ce_batch *b)
         CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));
     }
     for (auto &p : b->ba_s) CE_HIP(ctx, hipMalloc(&p, slots * 3 * p0 * sizeof(float)));
-    // pair scratch: 1 ac[3], 2 dc[3]
-    CE_HIP(ctx, hipMalloc(&b->ba_pp[1], P * 3 * p0 * sizeof(float)));
-    CE_HIP(ctx, hipMalloc(&b->ba_pp[2], P * 3 * p0 * sizeof(float)));
-    // blurred mask input, per image slot and level (persists like the PsychoImage)
-    for (int l = 0; l < b->ba_levels; l++) CE_HIP(ctx, hipMalloc(&b->ba_mask[l], slots * b->ba[l].plane * sizeof(float)));
+    // blurred mask input per image slot and level, the references' two mask-value planes per level (both persist like the
+    // PsychoImage)
+    for (int l = 0; l < b->ba_levels; l++) {
+        CE_HIP(ctx, hipMalloc(&b->ba_mask[l], slots * b->ba[l].plane * sizeof(float)));
+        CE_HIP(ctx, hipMalloc(&b->ba_mask_vals[l], (size_t)b->max_refs * 2 * b->ba[l].plane * sizeof(float)));
+    }
     b->ba_blocks = ((b->ba[0].w + 63) / 64) * ((b->ba[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ba_blk_max, P * b->ba_blocks * sizeof(float)));
     CE_HIP(ctx, hipMalloc(&b->ba_blk_sums, P * b->ba_blocks * 3 * sizeof(double)));
@@ -1256,8 +1261,16 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                       psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0);
         }
 
-        // ---- per pair ----
-        float *ac = b->ba_pp[1], *dc = b->ba_pp[2];
+        // mask input: DiffPrecompute of HF + UHF, blurred with sigma 2.7 - per image slot (the references' once per
+        // reference; cached with the PsychoImage for reference handles), into the level's own per-slot planes; then the
+        // references' mask values (FuzzyErosion + the two mask curves), also once per reference
+        const plane_sel s1{1, 0, 1};
+        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(nz), dim3(TPB), 0, psy, b->ba_s[0], g, n_refs_used, mr, z0);
+        if ((rc = launch_blur(ctx, b->ba_s[0], b->ba_s[1], b->ba_mask[l], g, s1, s1, s1, kMask, nz, n_refs_used, mr, 1, z0)) != CE_OK) return rc;
+        if (!cached)
+            CE_LAUNCH(ctx, "ba_mask_vals", k_ba_mask_vals, G(n_refs_used), dim3(TPB), 0, (const float *)b->ba_mask[l], b->ba_mask_vals[l], g);
+
+        // ---- per pair: Malta + L2 terms + CombineChannelsToDiffmap -> the level's diffmap ----
         // tile height: 64 rows / 512 threads for images that fill the chip with such tiles, else 32 rows / 256 threads
         // (CE_MALTA_ROWS=32|64 forces one: measurement knob)
         static const int forced_rows = [] {
@@ -1272,18 +1285,13 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         const uint32_t tiles_x = (d.w + MT - 1) / MT, tiles_y = (d.h + (uint32_t)malta_rows - 1) / (uint32_t)malta_rows;
         if ((rc = ce_build_xcd_list(b, n_pairs, tiles_x * tiles_y, &b->ba_work[l])) != CE_OK) return rc;
         if (malta_rows == 64)
-            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<64, 512>), dim3(b->ba_work[l].len), dim3(512), 0, psy, b->d_pair_ref, ac, dc, g, mr, P,
-                      mb, (const uint2 *)b->ba_work[l].d, tiles_x);
+            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<64, 512>), dim3(b->ba_work[l].len), dim3(512), 0, psy, b->d_pair_ref,
+                      (const float *)b->ba_mask[l], (const float *)b->ba_mask_vals[l], b->ba_diff[l], g, mr, mb,
+                      (const uint2 *)b->ba_work[l].d, tiles_x);
         else
-            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<32, 256>), dim3(b->ba_work[l].len), dim3(256), 0, psy, b->d_pair_ref, ac, dc, g, mr, P,
-                      mb, (const uint2 *)b->ba_work[l].d, tiles_x);
-        // mask input: DiffPrecompute of HF + UHF, blurred with sigma 2.7 - per image slot (the references' once per
-        // reference; cached with the PsychoImage for reference handles), into the level's own per-slot planes
-        const plane_sel s1{1, 0, 1};
-        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(nz), dim3(TPB), 0, psy, b->ba_s[0], g, n_refs_used, mr, z0);
-        if ((rc = launch_blur(ctx, b->ba_s[0], b->ba_s[1], b->ba_mask[l], g, s1, s1, s1, kMask, nz, n_refs_used, mr, 1, z0)) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "ba_mask_combine", k_ba_mask_combine, G(n_pairs), dim3(TPB), 0, (const float *)b->ba_mask[l], b->d_pair_ref, ac, dc,
-                  b->ba_diff[l], g, P, mr);
+            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<32, 256>), dim3(b->ba_work[l].len), dim3(256), 0, psy, b->d_pair_ref,
+                      (const float *)b->ba_mask[l], (const float *)b->ba_mask_vals[l], b->ba_diff[l], g, mr, mb,
+                      (const uint2 *)b->ba_work[l].d, tiles_x);
     }
     if (b->keep_ref_pyramid && !cached) {
         b->ba_ref_src = d_refs;

@@ -174,7 +174,7 @@ struct ce_batch {
     float *ba_diff[2] = {};   // [pair][plane_l]      diffmaps
     float *ba_mask[2] = {};   // [slot][plane_l]      blurred mask input (DiffPrecompute of HF + UHF, sigma 2.7)
     float *ba_s[3] = {};      // per-slot scratch, 3 planes each
-    float *ba_pp[9] = {};     // per-pair scratch
+    float *ba_mask_vals[2] = {};  // [ref][2][plane_l]    maskval / dc_maskval of the references (FuzzyErosion + mask curves)
     float *ba_blk_max = nullptr;
     double *ba_blk_sums = nullptr;
     double *ba_pnorm = nullptr;  // [pair] libjxl 3-norm of the last run

@@ -123,14 +123,14 @@ def butteraugli_bytes(b: Bucket, acc: Dict[str, float]):
         _add(acc, "ba_blur_v_mf", slots * n * (12 + 8 + 12 + 8))  # row-blurred + raw MF X,Y in; MF x3 + raw HF x2 out
         _add(acc, "ba_blur_h7", slots * n * (8 + 8))
         _add(acc, "ba_blur_v_hf", slots * n * (8 + 8 + 16))      # row-blurred + raw HF in; HF x2 + UHF x2 out
-        # per pair: Malta + L2 terms read the ten PsychoImage planes of both images, write AC and DC triples
-        _add(acc, "ba_malta_l2", n * (40 * P + 40 * R + 24 * P))
-        # mask input per image slot: four planes in, one out; its sigma-2.7 blur; then per pair the combine reads the
-        # distorted image's blurred plane (the reference's once per reference), AC and DC triples, writes the diffmap
+        # mask input per image slot: four planes in, one out; its sigma-2.7 blur; the references' two mask-value planes
         _add(acc, "ba_mask_pre", slots * n * (16 + 4))
         _add(acc, "ba_blur_h13", slots * n * 8)
         _add(acc, "ba_blur_v13", slots * n * 8)
-        _add(acc, "ba_mask_combine", n * (4 * R + P * (4 + 12 + 12 + 4)))
+        _add(acc, "ba_mask_vals", R * n * (4 + 8))
+        # per pair: Malta + L2 terms + CombineChannelsToDiffmap read the ten PsychoImage planes and the blurred mask plane
+        # of both images and the reference's two mask-value planes, write the diffmap (the AC / DC triples stay in registers)
+        _add(acc, "ba_malta_l2", n * ((40 + 4) * P + (40 + 4 + 8) * R + 4 * P))
     n0 = b.px
     has_sub = len(lv) == 2
     _add(acc, "ba_final", n0 * P * (4 + (4 + 1 if has_sub else 0)))
