@@ -732,11 +732,16 @@ __device__ __forceinline__ void malta_rows_xy(const ba_f2 *__restrict__ base, ba
 // MR rows of outputs per block, NT threads (32 threads per output row pair-column, NT / 32 rows per step):
 //   <32, 256>: 72 x 40 tile (1.41x halo), 39 KB LDS, four blocks per CU
 //   <64, 512>: 72 x 72 tile (1.27x halo: 10 % fewer pre-scalings), 73 KB LDS, two blocks of eight waves per CU
-template <int MR, int NT>
+// FINAL (the full-resolution level, launched after the half-resolution one): the pixel's diffmap value takes the
+// half-resolution diffmap (AddSupersampled2x, weight 0.5) and goes straight into the score reductions - max, sum d^3, d^6,
+// d^12 per tile - instead of to memory; !FINAL (the half-resolution level) writes its diffmap.
+template <int MR, int NT, bool FINAL>
 __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const float *__restrict__ psy, const uint32_t *__restrict__ pair_ref,
                                                            const float *__restrict__ blurred, const float *__restrict__ mask_vals,
                                                            float *__restrict__ diffmap, geom g, uint32_t max_refs,
-                                                           malta_bands mb, const uint2 *__restrict__ work, uint32_t tiles_x)
+                                                           malta_bands mb, const uint2 *__restrict__ work, uint32_t tiles_x,
+                                                           const float *__restrict__ sub_map, geom gs, int has_sub,
+                                                           float *__restrict__ blk_max, double *__restrict__ blk_sums, uint32_t n_blocks)
 {
     constexpr int MLR = MR + 2 * MH, RSTEP = NT / 32;  // tile rows; output rows per step of the whole block
     __shared__ __attribute__((aligned(16))) ba_f2 s[MLR * ML];
@@ -800,6 +805,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
     }
     const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
     const float hf_asymmetry = 1.0f;
+    float red_m = 0.0f;  // the diffmap is non-negative
+    double red_s3 = 0.0, red_s6 = 0.0, red_s12 = 0.0;
 #pragma unroll 1
     for (int sub = 0; sub < MR / RSTEP; sub++)
 #pragma unroll
@@ -847,7 +854,55 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
         dc0 *= xmul;
         const float mc_dc = dc0 * dc_maskval + dc1 * dc_maskval + dc2 * dc_maskval;
         const float mc_ac = ac0 * maskval + ac1 * maskval + ac2 * maskval;
-        diffmap[(size_t)p * g.plane + o] = sqrtf(mc_dc + mc_ac);
+        float d = sqrtf(mc_dc + mc_ac);
+        if (!FINAL) {
+            diffmap[(size_t)p * g.plane + o] = d;
+            continue;
+        }
+        if (has_sub) {  // AddSupersampled2x
+            const float kHeuristicMixingValue = 0.3f, wgt = 0.5f;
+            d *= 1.0f - kHeuristicMixingValue * wgt;
+            d += wgt * sub_map[(size_t)p * gs.plane + (size_t)(y / 2) * gs.pitch + x / 2];
+        }
+        const double dd = d, d3 = dd * dd * dd, d6 = d3 * d3;
+        red_s3 += d3;
+        red_s6 += d6;
+        red_s12 += d6 * d6;
+        red_m = fmaxf(red_m, d);
+    }
+    if (FINAL) {  // one partial per (pair, tile): thread order, then wave order - fixed, so the sums are reproducible
+        __shared__ float s_max[NT / 64];
+        __shared__ double s_sum[3][NT / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            red_m = fmaxf(red_m, __shfl_down(red_m, off, 64));
+            red_s3 += __shfl_down(red_s3, off, 64);
+            red_s6 += __shfl_down(red_s6, off, 64);
+            red_s12 += __shfl_down(red_s12, off, 64);
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            s_max[wv] = red_m;
+            s_sum[0][wv] = red_s3;
+            s_sum[1][wv] = red_s6;
+            s_sum[2][wv] = red_s12;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mm = s_max[0];
+            double sa = 0, sb = 0, sc = 0;
+            for (int k = 0; k < NT / 64; k++) {
+                mm = fmaxf(mm, s_max[k]);
+                sa += s_sum[0][k];
+                sb += s_sum[1][k];
+                sc += s_sum[2][k];
+            }
+            const size_t bi = (size_t)p * n_blocks + wi.x;
+            blk_max[bi] = mm;
+            blk_sums[bi * 3] = sa;
+            blk_sums[bi * 3 + 1] = sb;
+            blk_sums[bi * 3 + 2] = sc;
+        }
     }
 }
 
@@ -927,70 +982,6 @@ __global__ __launch_bounds__(TPB) void k_ba_mask_vals(const float *__restrict__ 
     c = 0.505054525019 / ((3.87449418804 * val) + 0.20025578522);
     rv = kGlobalScale * (1.0 + c);
     vals[((size_t)z * 2 + 1) * g.plane + o] = (float)(rv * rv);  // dc_maskval
-}
-
-constexpr int BF_ROWS = 32;  // rows per block of k_ba_final
-// AddSupersampled2x (weight 0.5) fused with the final reductions: max, sum d^3, d^6, d^12
-__global__ __launch_bounds__(TPB) void k_ba_final(float *__restrict__ diffmap, const float *__restrict__ sub, geom g, geom gs,
-                                                  int has_sub, float *__restrict__ blk_max, double *__restrict__ blk_sums,
-                                                  uint32_t n_blocks)
-{
-    __shared__ float s_max[TPB / 64];
-    __shared__ double s_sum[3][TPB / 64];
-    const uint32_t p = blockIdx.z;
-    // block = 64 columns x 32 rows, a thread walks 8 rows (stride 4): one block reduction per 2048 pixels
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    float m = 0.0f;  // the diffmap is non-negative
-    double s3 = 0.0, s6 = 0.0, s12 = 0.0;
-#pragma unroll
-    for (int k = 0; k < BF_ROWS / 4; k++) {
-        const uint32_t y = blockIdx.y * BF_ROWS + 4 * k + (threadIdx.x >> 6);
-        if (x < g.w && y < g.h) {
-            const size_t o = (size_t)p * g.plane + (size_t)y * g.pitch + x;
-            float d = diffmap[o];
-            if (has_sub) {
-                const float kHeuristicMixingValue = 0.3f, wgt = 0.5f;
-                d *= 1.0f - kHeuristicMixingValue * wgt;
-                d += wgt * sub[(size_t)p * gs.plane + (size_t)(y / 2) * gs.pitch + x / 2];
-                diffmap[o] = d;
-            }
-            const double dd = d, d3 = dd * dd * dd, d6 = d3 * d3;
-            s3 += d3;
-            s6 += d6;
-            s12 += d6 * d6;
-            m = fmaxf(m, d);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m = fmaxf(m, __shfl_down(m, off, 64));
-        s3 += __shfl_down(s3, off, 64);
-        s6 += __shfl_down(s6, off, 64);
-        s12 += __shfl_down(s12, off, 64);
-    }
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_max[wv] = m;
-        s_sum[0][wv] = s3;
-        s_sum[1][wv] = s6;
-        s_sum[2][wv] = s12;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float mm = s_max[0];
-        double a = 0, b = 0, c = 0;
-        for (int k = 0; k < TPB / 64; k++) {
-            mm = fmaxf(mm, s_max[k]);
-            a += s_sum[0][k];
-            b += s_sum[1][k];
-            c += s_sum[2][k];
-        }
-        const size_t bi = (size_t)p * n_blocks + blockIdx.y * gridDim.x + blockIdx.x;
-        blk_max[bi] = mm;
-        blk_sums[bi * 3] = a;
-        blk_sums[bi * 3 + 1] = b;
-        blk_sums[bi * 3 + 2] = c;
-    }
 }
 
 // one block per pair: max and the three power sums over the block partials (fixed order), then the norms
@@ -1163,7 +1154,7 @@ static int ba_allocate(ce_batch *b)
     for (int l = 0; l < b->ba_levels; l++) {
         if (l == 1) CE_HIP(ctx, hipMalloc(&b->ba_lin[l], slots * 3 * b->ba[l].plane * sizeof(float)));  // level 0 reads u8
         CE_HIP(ctx, hipMalloc(&b->ba_psy[l], slots * PSY * b->ba[l].plane * sizeof(float)));
-        CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));
+        if (l == 1) CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));  // the full-resolution diffmap is never stored
     }
     for (auto &p : b->ba_s) CE_HIP(ctx, hipMalloc(&p, slots * 3 * p0 * sizeof(float)));
     // blurred mask input per image slot and level, the references' two mask-value planes per level (both persist like the
@@ -1218,7 +1209,10 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     const malta_params mMfY = make_malta(37.0819870399, 37.0819870399, 130262059.556, true);
     const malta_params mMfX = make_malta(8246.75321353, 8246.75321353, 1009002.70582, true);
 
-    for (int l = 0; l < b->ba_levels; l++) {
+    // half resolution first: the full-resolution level's Malta kernel folds that diffmap into its own values and reduces
+    // them to the score partials
+    uint32_t final_tiles = 0;
+    for (int l = b->ba_levels - 1; l >= 0; l--) {
         const auto &d = b->ba[l];
         const geom g{d.w, d.h, d.pitch, d.plane};
         const dim3 gx((d.w + 63) / 64, (d.h + 3) / 4, 1);
@@ -1284,14 +1278,27 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         mb.p[1][0] = mUhfY; mb.p[1][1] = mHfY; mb.p[1][2] = mMfY;
         const uint32_t tiles_x = (d.w + MT - 1) / MT, tiles_y = (d.h + (uint32_t)malta_rows - 1) / (uint32_t)malta_rows;
         if ((rc = ce_build_xcd_list(b, n_pairs, tiles_x * tiles_y, &b->ba_work[l])) != CE_OK) return rc;
-        if (malta_rows == 64)
-            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<64, 512>), dim3(b->ba_work[l].len), dim3(512), 0, psy, b->d_pair_ref,
-                      (const float *)b->ba_mask[l], (const float *)b->ba_mask_vals[l], b->ba_diff[l], g, mr, mb,
-                      (const uint2 *)b->ba_work[l].d, tiles_x);
-        else
-            CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<32, 256>), dim3(b->ba_work[l].len), dim3(256), 0, psy, b->d_pair_ref,
-                      (const float *)b->ba_mask[l], (const float *)b->ba_mask_vals[l], b->ba_diff[l], g, mr, mb,
-                      (const uint2 *)b->ba_work[l].d, tiles_x);
+        const bool has_sub = b->ba_levels == 2;
+        const auto &ds = b->ba[has_sub ? 1 : 0];
+        const geom gsub{ds.w, ds.h, ds.pitch, ds.plane};
+#define CE_MALTA_LAUNCH(ROWS, THREADS, FINAL)                                                                                      \
+    CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<ROWS, THREADS, FINAL>), dim3(b->ba_work[l].len), dim3(THREADS), 0, psy, b->d_pair_ref, \
+              (const float *)b->ba_mask[l], (const float *)b->ba_mask_vals[l], FINAL ? (float *)nullptr : b->ba_diff[1], g, mr, mb,       \
+              (const uint2 *)b->ba_work[l].d, tiles_x, FINAL ? (const float *)b->ba_diff[1] : (const float *)nullptr, gsub,               \
+              has_sub ? 1 : 0, b->ba_blk_max, b->ba_blk_sums, b->ba_blocks)
+        if (l == 0) {
+            final_tiles = tiles_x * tiles_y;
+            if (malta_rows == 64)
+                CE_MALTA_LAUNCH(64, 512, true);
+            else
+                CE_MALTA_LAUNCH(32, 256, true);
+        } else {
+            if (malta_rows == 64)
+                CE_MALTA_LAUNCH(64, 512, false);
+            else
+                CE_MALTA_LAUNCH(32, 256, false);
+        }
+#undef CE_MALTA_LAUNCH
     }
     if (b->keep_ref_pyramid && !cached) {
         b->ba_ref_src = d_refs;
@@ -1299,15 +1306,8 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         b->ba_ref_intensity = intensity_target;
     }
     const auto &d0 = b->ba[0];
-    const geom g0{d0.w, d0.h, d0.pitch, d0.plane};
-    const bool has_sub = b->ba_levels == 2;
-    const auto &d1 = b->ba[has_sub ? 1 : 0];
-    const geom g1{d1.w, d1.h, d1.pitch, d1.plane};
-    const dim3 gf((d0.w + 63) / 64, (d0.h + BF_ROWS - 1) / BF_ROWS, n_pairs);
-    CE_LAUNCH(ctx, "ba_final", k_ba_final, gf, dim3(TPB), 0, b->ba_diff[0], b->ba_diff[has_sub ? 1 : 0], g0, g1, has_sub ? 1 : 0,
-              b->ba_blk_max, b->ba_blk_sums, b->ba_blocks);
     CE_LAUNCH(ctx, "ba_score", k_ba_score, dim3(n_pairs), dim3(TPB), 0, b->ba_blk_max, b->ba_blk_sums, b->d_scores, b->ba_pnorm,
-              b->ba_blocks, gf.x * gf.y, (double)d0.w * (double)d0.h);
+              b->ba_blocks, final_tiles, (double)d0.w * (double)d0.h);
     CE_HIP(ctx, hipGetLastError());
     return CE_OK;
 }

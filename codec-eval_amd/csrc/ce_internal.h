@@ -171,7 +171,7 @@ struct ce_batch {
     int ba_levels = 0;
     float *ba_lin[2] = {};    // [slot][3][plane_l]
     float *ba_psy[2] = {};    // [slot][10][plane_l]  PsychoImage
-    float *ba_diff[2] = {};   // [pair][plane_l]      diffmaps
+    float *ba_diff[2] = {};   // [pair][plane_1]      the half-resolution diffmap ([1]; the full-resolution one is reduced in registers)
     float *ba_mask[2] = {};   // [slot][plane_l]      blurred mask input (DiffPrecompute of HF + UHF, sigma 2.7)
     float *ba_s[3] = {};      // per-slot scratch, 3 planes each
     float *ba_mask_vals[2] = {};  // [ref][2][plane_l]    maskval / dc_maskval of the references (FuzzyErosion + mask curves)

@@ -129,11 +129,12 @@ def butteraugli_bytes(b: Bucket, acc: Dict[str, float]):
         _add(acc, "ba_blur_v13", slots * n * 8)
         _add(acc, "ba_mask_vals", R * n * (4 + 8))
         # per pair: Malta + L2 terms + CombineChannelsToDiffmap read the ten PsychoImage planes and the blurred mask plane
-        # of both images and the reference's two mask-value planes, write the diffmap (the AC / DC triples stay in registers)
-        _add(acc, "ba_malta_l2", n * ((40 + 4) * P + (40 + 4 + 8) * R + 4 * P))
-    n0 = b.px
-    has_sub = len(lv) == 2
-    _add(acc, "ba_final", n0 * P * (4 + (4 + 1 if has_sub else 0)))
+        # of both images and the reference's two mask-value planes (the AC / DC triples stay in registers); the
+        # half-resolution level writes its diffmap, the full-resolution level reads that (a quarter of its pixels) and
+        # reduces its own values to the score partials without storing them
+        has_sub = len(lv) == 2
+        io = 4 * P if l == 1 else (1 * P if has_sub else 0)
+        _add(acc, "ba_malta_l2", n * ((40 + 4) * P + (40 + 4 + 8) * R) + n * io)
 
 
 def step_bytes(buckets: Iterable[Bucket], metrics: Iterable[str], xyb_roundtrip: bool = False) -> Dict[str, float]:
