@@ -428,10 +428,24 @@ __device__ __forceinline__ float maximum_clamp(float v, float maxval)
 // Arithmetic per element is exactly that of k_ba_blur_v followed by the old pointwise kernels.
 enum { EPI_LF = 0, EPI_MF = 1, EPI_HF = 2 };
 
+// MaskPsychoImage's input at one pixel: DiffPrecompute of (UHF + HF) of X and Y (pointwise on the FINAL band values)
+__device__ __forceinline__ float mask_pre_one(float uhf0, float hf0, float uhf1, float hf1)
+{
+    const float muls[3] = {2.5f, 0.4f, 0.4f};
+    const float xdiff = (uhf0 + hf0) * muls[0];
+    const float ydiff = uhf1 * muls[1] + hf1 * muls[2];
+    const float m = sqrtf(xdiff * xdiff + ydiff * ydiff);
+    const float kMul = 6.19424080439f, kBias = 12.61050594197f;
+    const float bias = kMul * kBias;
+    const float sqrt_bias = sqrtf(bias);
+    return sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
+}
+
 template <int LEN, int EPI>
 __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict__ tmp, const float *__restrict__ xyb,
                                                          float *__restrict__ psy, geom g, blur_kernel bk, float inv_wsum,
-                                                         uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
+                                                         uint32_t n_refs_used, uint32_t max_refs, uint32_t z0,
+                                                         float *__restrict__ mask_in)
 {
     constexpr int NP = EPI == EPI_HF ? 2 : 3;
     // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
@@ -526,21 +540,29 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
             } else {
                 const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
                 const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
+                float hf0_out, uhf0_out, hf1_out, uhf1_out;
                 {
                     const float hf = res[0][part][o];
                     const float uhf = q[HF0 * pl] - hf;
-                    q[HF0 * pl] = remove_range(kRemoveHfRange, hf);
-                    q[UHF0 * pl] = remove_range(kRemoveUhfRange, uhf);
+                    hf0_out = remove_range(kRemoveHfRange, hf);
+                    uhf0_out = remove_range(kRemoveUhfRange, uhf);
+                    q[HF0 * pl] = hf0_out;
+                    q[UHF0 * pl] = uhf0_out;
                 }
                 {
                     float hf = maximum_clamp(res[1][part][o], kMaxclampHf);
                     float uhf = q[HF1 * pl] - hf;
                     uhf = maximum_clamp(uhf, kMaxclampUhf);
                     uhf *= kMulYUhf;
+                    uhf1_out = uhf;
                     q[UHF1 * pl] = uhf;
                     hf *= kMulYHf;
-                    q[HF1 * pl] = amplify_range(kAddHfRange, hf);
+                    hf1_out = amplify_range(kAddHfRange, hf);
+                    q[HF1 * pl] = hf1_out;
                 }
+                // the four band values are final here: the mask input of this pixel (one plane per image slot) costs no
+                // extra pass over the PsychoImage
+                mask_in[(size_t)slot * pl + (size_t)(gy0 + o) * g.pitch + gx] = mask_pre_one(uhf0_out, hf0_out, uhf1_out, hf1_out);
             }
         }
     }
@@ -908,27 +930,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
 
 // ---- per pair: mask -----------------------------------------------------------------------------------------------
 // DiffPrecompute(sqrt(xdiff^2 + ydiff^2)) of the reference (m0) and the test image (m1) of a pair
-__device__ __forceinline__ float mask_pre_one(const float *__restrict__ a, size_t plane)
-{
-    const float muls[3] = {2.5f, 0.4f, 0.4f};
-    const float xdiff = (a[UHF0 * plane] + a[HF0 * plane]) * muls[0];
-    const float ydiff = a[UHF1 * plane] * muls[1] + a[HF1 * plane] * muls[2];
-    const float m = sqrtf(xdiff * xdiff + ydiff * ydiff);
-    const float kMul = 6.19424080439f, kBias = 12.61050594197f;
-    const float bias = kMul * kBias;
-    const float sqrt_bias = sqrtf(bias);
-    return sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
-}
-
-// per IMAGE SLOT (the mask input depends on one image only, so a reference's is computed once per reference - and kept
-// by a reference handle - instead of once per pair)
-__global__ __launch_bounds__(TPB) void k_ba_mask_pre(const float *__restrict__ psy, float *__restrict__ m, geom g, uint32_t n_refs_used,
-                                                     uint32_t max_refs, uint32_t z0)
-{
-    const uint32_t slot = slot_of(blockIdx.z + z0, n_refs_used, max_refs);
-    BA_XY;
-    m[(size_t)slot * g.plane + o] = mask_pre_one(psy + (size_t)slot * PSY * g.plane + o, g.plane);
-}
 
 // StoreMin3: keep the three smallest values seen, sorted.  The state (min0 <= min1 <= min2) starts sorted for the
 // non-negative inputs of the mask, so the insertion is a min/max network - no branches, no indexed temporaries
@@ -1244,23 +1245,23 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
             CE_LAUNCH(ctx, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1, z0);
             CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy, g,
-                      kLf, inv_weight_sum(kLf), n_refs_used, mr, z0);
+                      kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr);
             CE_LAUNCH(ctx, "ba_blur_h15", k_ba_blur_h<15>, gh3, dim3(TPB), 0, (const float *)psy, sA, g, sMf, s3, kHf, inv_weight_sum(kHf),
                       n_refs_used, mr, 1, z0);
             CE_LAUNCH(ctx, "ba_blur_v_mf", (k_ba_blur_v_split<15, EPI_MF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
-                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0);
+                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr);
             CE_LAUNCH(ctx, "ba_blur_h7", k_ba_blur_h<7>, gh2, dim3(TPB), 0, (const float *)psy, sA, g, sHf, s2, kUhf, inv_weight_sum(kUhf),
                       n_refs_used, mr, 1, z0);
             CE_LAUNCH(ctx, "ba_blur_v_hf", (k_ba_blur_v_split<7, EPI_HF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
-                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0);
+                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, b->ba_s[1]);
         }
 
-        // mask input: DiffPrecompute of HF + UHF, blurred with sigma 2.7 - per image slot (the references' once per
-        // reference; cached with the PsychoImage for reference handles), into the level's own per-slot planes; then the
+        // mask input: DiffPrecompute of HF + UHF (written by the HF split's epilogue into ba_s[1]), blurred with sigma 2.7 -
+        // per image slot (the references' once per reference; cached with the PsychoImage for reference handles), into
+        // the level's own per-slot planes; then the
         // references' mask values (FuzzyErosion + the two mask curves), also once per reference
         const plane_sel s1{1, 0, 1};
-        CE_LAUNCH(ctx, "ba_mask_pre", k_ba_mask_pre, G(nz), dim3(TPB), 0, psy, b->ba_s[0], g, n_refs_used, mr, z0);
-        if ((rc = launch_blur(ctx, b->ba_s[0], b->ba_s[1], b->ba_mask[l], g, s1, s1, s1, kMask, nz, n_refs_used, mr, 1, z0)) != CE_OK) return rc;
+        if ((rc = launch_blur(ctx, b->ba_s[1], b->ba_s[0], b->ba_mask[l], g, s1, s1, s1, kMask, nz, n_refs_used, mr, 1, z0)) != CE_OK) return rc;
         if (!cached)
             CE_LAUNCH(ctx, "ba_mask_vals", k_ba_mask_vals, G(n_refs_used), dim3(TPB), 0, (const float *)b->ba_mask[l], b->ba_mask_vals[l], g);
 

@@ -122,9 +122,8 @@ def butteraugli_bytes(b: Bucket, acc: Dict[str, float]):
         _add(acc, "ba_blur_h15", slots * n * (12 + 12))
         _add(acc, "ba_blur_v_mf", slots * n * (12 + 8 + 12 + 8))  # row-blurred + raw MF X,Y in; MF x3 + raw HF x2 out
         _add(acc, "ba_blur_h7", slots * n * (8 + 8))
-        _add(acc, "ba_blur_v_hf", slots * n * (8 + 8 + 16))      # row-blurred + raw HF in; HF x2 + UHF x2 out
-        # mask input per image slot: four planes in, one out; its sigma-2.7 blur; the references' two mask-value planes
-        _add(acc, "ba_mask_pre", slots * n * (16 + 4))
+        _add(acc, "ba_blur_v_hf", slots * n * (8 + 8 + 16 + 4))  # row-blurred + raw HF in; HF x2 + UHF x2 + the mask input out
+        # the mask input's sigma-2.7 blur per image slot; the references' two mask-value planes
         _add(acc, "ba_blur_h13", slots * n * 8)
         _add(acc, "ba_blur_v13", slots * n * 8)
         _add(acc, "ba_mask_vals", R * n * (4 + 8))
