@@ -426,6 +426,13 @@ __device__ __forceinline__ float maximum_clamp(float v, float maxval)
 //                                   range-shaped mf -> psy MF
 //   EPI_HF (2 planes, sigma 1.564): hf = blur(hf_raw);  uhf = hf_raw - hf, clamps / ranges -> psy UHF, HF
 // Arithmetic per element is exactly that of k_ba_blur_v followed by the old pointwise kernels.
+//
+// HV (the MF and HF stages, 15 and 7 taps): the ROW blur runs in the same kernel - the raw band's tile (64 + LEN - 1 rows,
+// 64 + 16 columns, zero outside the image) is staged in LDS, every tile row is filtered into the column pass's tile
+// (taps in ascending order, border scale of k_ba_blur_h: the same sums), so the row-blurred planes never travel through
+// HBM.  A fused stage reads its raw band with a halo, so no stage may overwrite its own input: the raw bands live in
+// scratch planes (`aux`): LF stage -> raw MF -> aux_out;  MF stage: aux_in -> MF (psy), raw HF -> aux_out;  HF stage:
+// aux_in -> HF, UHF (psy), mask input.  (The 33-tap LF stage keeps its separate row pass: its halo would be half a tile.)
 enum { EPI_LF = 0, EPI_MF = 1, EPI_HF = 2 };
 
 // MaskPsychoImage's input at one pixel: DiffPrecompute of (UHF + HF) of X and Y (pointwise on the FINAL band values)
@@ -441,32 +448,36 @@ __device__ __forceinline__ float mask_pre_one(float uhf0, float hf0, float uhf1,
     return sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
 }
 
-template <int LEN, int EPI>
+template <int LEN, int EPI, bool HV>
 __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict__ tmp, const float *__restrict__ xyb,
                                                          float *__restrict__ psy, geom g, blur_kernel bk, float inv_wsum,
                                                          uint32_t n_refs_used, uint32_t max_refs, uint32_t z0,
-                                                         float *__restrict__ mask_in)
+                                                         float *__restrict__ mask_in, float *__restrict__ aux_out)
 {
     constexpr int NP = EPI == EPI_HF ? 2 : 3;
     // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
     constexpr int off = LEN / 2, TW = 64, TR = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
+    // HV: the staged input is 4 or 8 columns wider on each side (>= off, and its rows load as aligned float4)
+    constexpr int LEFT = off <= 4 ? 4 : 8, IW = HV ? TW + 2 * LEFT : TW;
+    static_assert(!HV || off <= LEFT, "row-pass halo");
     __shared__ __attribute__((aligned(16))) float tile[RAW * TW];
+    __shared__ __attribute__((aligned(16))) float in_t[HV ? RAW * IW : 4];
     const uint32_t slot = slot_of(blockIdx.z + z0, n_refs_used, max_refs);
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
     const int c = threadIdx.x & 63, wv = threadIdx.x >> 6, gx = x0 + c;
     const bool col_live = gx < (int)g.w;
     float res[NP][PARTS][BW_OUT];
-    // The tile of plane q+1 is fetched (aligned float4 pieces of the rows, zero outside the image) into registers
+    // The (input) tile of plane q+1 is fetched (aligned float4 pieces of the rows, zero outside the image) into registers
     // while plane q is filtered: NF float4 per thread.
-    constexpr int NF = (RAW * (TW / 4) + TPB - 1) / TPB;
+    constexpr int NF = (RAW * (IW / 4) + TPB - 1) / TPB;
     float4 pf[NF];
     auto fetch = [&](int q) {
-        const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes of this slot
+        const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes (HV: the raw band) of this slot
 #pragma unroll
         for (int m = 0; m < NF; m++) {
-            const int i = m * TPB + (int)threadIdx.x, r = i / (TW / 4), X = x0 + 4 * (i % (TW / 4)), Y = y0 - off + r;
+            const int i = m * TPB + (int)threadIdx.x, r = i / (IW / 4), X = x0 - (HV ? LEFT : 0) + 4 * (i % (IW / 4)), Y = y0 - off + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < RAW && Y >= 0 && Y < (int)g.h && X < (int)g.pitch) v = *reinterpret_cast<const float4 *>(p + (size_t)Y * g.pitch + X);
+            if (r < RAW && Y >= 0 && Y < (int)g.h && X >= 0 && X < (int)g.pitch) v = *reinterpret_cast<const float4 *>(p + (size_t)Y * g.pitch + X);
             v.x = X < (int)g.w ? v.x : 0.0f;
             v.y = X + 1 < (int)g.w ? v.y : 0.0f;
             v.z = X + 2 < (int)g.w ? v.z : 0.0f;
@@ -474,17 +485,40 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
             pf[m] = v;
         }
     };
-    fetch(0);
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-        if (q) __syncthreads();
+    auto stash = [&]() {  // the fetched pieces -> LDS (HV: the input tile, else the column pass's tile)
 #pragma unroll
         for (int m = 0; m < NF; m++) {
             const int i = m * TPB + (int)threadIdx.x;
-            if (i < RAW * (TW / 4)) *reinterpret_cast<float4 *>(tile + 4 * i) = pf[m];
+            if (i < RAW * (IW / 4)) *reinterpret_cast<float4 *>((HV ? in_t : tile) + 4 * i) = pf[m];
         }
-        if (q + 1 < NP) fetch(q + 1);
+    };
+    // HV: the column of this thread is the same in every row it filters (TPB is a multiple of TW)
+    const float scale_x = (HV && col_live) ? border_scale<LEN>(bk, gx, (int)g.w, inv_wsum) : 0.0f;
+    fetch(0);
+    if (HV) {
+        stash();
         __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+        if (HV) {
+            // row pass of every tile row: taps in ascending order, zero outside the image (x + 0.0f == x), border scale
+#pragma unroll 1
+            for (int i = threadIdx.x; i < RAW * TW; i += TPB) {
+                const float *src = in_t + (i / TW) * IW + c + LEFT - off;
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < LEN; j++) sum += src[j] * bk.k[j];
+                tile[i] = sum * scale_x;  // scale_x = 0 right of the image: the column pass sees zeros there
+            }
+            __syncthreads();  // the tile is complete; the input tile may be overwritten
+            if (q + 1 < NP) fetch(q + 1);
+        } else {
+            if (q) __syncthreads();
+            stash();
+            if (q + 1 < NP) fetch(q + 1);
+            __syncthreads();
+        }
 #pragma unroll
         for (int part = 0; part < PARTS; part++) {
             const int ly = 32 * part + 8 * wv, gy0 = y0 + ly;
@@ -501,6 +535,10 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                 }
             }
         }
+        if (HV && q + 1 < NP) {
+            stash();
+            __syncthreads();  // the next input tile is complete; this plane's tile has been read
+        }
     }
     if (!col_live) return;
     const size_t pl = g.plane;
@@ -513,12 +551,14 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
         for (int o = 0; o < BW_OUT; o++) {
             if (gy0 + o >= (int)g.h) break;
             float *q = ps + (size_t)o * g.pitch;
+            // this pixel in the 3-plane scratch sets (raw bands in / out)
+            const size_t ao = (size_t)slot * 3 * pl + (size_t)(gy0 + o) * g.pitch + gx;
             if (EPI == EPI_LF) {
                 const float *xs = xyb + (size_t)slot * 3 * pl + (size_t)(gy0 + o) * g.pitch + gx;
                 const float lx = res[0][part][o], ly = res[1][part][o], lb = res[2][part][o];
-                q[MF0 * pl] = xs[0] - lx;
-                q[MF1 * pl] = xs[pl] - ly;
-                q[MF2 * pl] = xs[2 * pl] - lb;
+                aux_out[ao] = xs[0] - lx;  // raw MF: the MF stage reads it with a halo, so it cannot live where MF is written
+                aux_out[ao + pl] = xs[pl] - ly;
+                aux_out[ao + 2 * pl] = xs[2 * pl] - lb;
                 // XybLowFreqToVals
                 const float xmul = 33.832837186260f, ymul = 14.458268100570f, bmul = 49.87984651440f, y_to_b_mul = -0.362267051518f;
                 const float bb = __builtin_fmaf(y_to_b_mul, ly, lb);
@@ -528,22 +568,22 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
             } else if (EPI == EPI_MF) {
                 const float kRemoveMfRange = 0.29f, kAddMfRange = 0.1f;
                 const float mf0 = res[0][part][o], mf1 = res[1][part][o];
-                const float hf0 = q[MF0 * pl] - mf0, hf1 = q[MF1 * pl] - mf1;
+                const float hf0 = tmp[ao] - mf0, hf1 = tmp[ao + pl] - mf1;
                 q[MF0 * pl] = remove_range(kRemoveMfRange, mf0);
                 q[MF1 * pl] = amplify_range(kAddMfRange, mf1);
                 q[MF2 * pl] = res[2][part][o];
                 // SuppressXByY(hf[1], &hf[0])
                 const float suppress = 46.0f, sv = 0.653020556257f, one_minus_s = 1.0f - 0.653020556257f;
                 const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf1, hf1, suppress), one_minus_s, sv);
-                q[HF0 * pl] = scaler * hf0;
-                q[HF1 * pl] = hf1;
+                aux_out[ao] = scaler * hf0;  // raw HF, for the HF stage
+                aux_out[ao + pl] = hf1;
             } else {
                 const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
                 const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
                 float hf0_out, uhf0_out, hf1_out, uhf1_out;
                 {
                     const float hf = res[0][part][o];
-                    const float uhf = q[HF0 * pl] - hf;
+                    const float uhf = tmp[ao] - hf;
                     hf0_out = remove_range(kRemoveHfRange, hf);
                     uhf0_out = remove_range(kRemoveUhfRange, uhf);
                     q[HF0 * pl] = hf0_out;
@@ -551,7 +591,7 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                 }
                 {
                     float hf = maximum_clamp(res[1][part][o], kMaxclampHf);
-                    float uhf = q[HF1 * pl] - hf;
+                    float uhf = tmp[ao + pl] - hf;
                     uhf = maximum_clamp(uhf, kMaxclampUhf);
                     uhf *= kMulYUhf;
                     uhf1_out = uhf;
@@ -1233,27 +1273,26 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                       sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
         }
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
-        const plane_sel sMf{PSY, MF0, 3}, sHf{PSY, HF0, 2}, s2{3, 0, 2};
         // SeparateFrequencies: row blur of a band, then column blur fused with the pointwise split (k_ba_blur_v_split)
         {
             if (kLf.len != 33 || kHf.len != 15 || kUhf.len != 7) {
                 ctx->err = "unexpected blur kernel length";
                 return CE_ERR_BACKEND;
             }
-            const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), nz * 3), gh2(gh3.x, gh3.y, nz * 2);
+            const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), nz * 3);
             const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, nz);
+            float *sB = b->ba_s[1];
+            // LF: row pass sC -> sA, column pass + split: LF -> psy, raw MF -> sB
             CE_LAUNCH(ctx, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1, z0);
-            CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy, g,
-                      kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr);
-            CE_LAUNCH(ctx, "ba_blur_h15", k_ba_blur_h<15>, gh3, dim3(TPB), 0, (const float *)psy, sA, g, sMf, s3, kHf, inv_weight_sum(kHf),
-                      n_refs_used, mr, 1, z0);
-            CE_LAUNCH(ctx, "ba_blur_v_mf", (k_ba_blur_v_split<15, EPI_MF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
-                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr);
-            CE_LAUNCH(ctx, "ba_blur_h7", k_ba_blur_h<7>, gh2, dim3(TPB), 0, (const float *)psy, sA, g, sHf, s2, kUhf, inv_weight_sum(kUhf),
-                      n_refs_used, mr, 1, z0);
-            CE_LAUNCH(ctx, "ba_blur_v_hf", (k_ba_blur_v_split<7, EPI_HF>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
-                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, b->ba_s[1]);
+            CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy,
+                      g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
+            // MF: row + column pass of raw MF (sB) + split: MF -> psy, raw HF -> sA (its old contents are dead)
+            CE_LAUNCH(ctx, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true>), gvs, dim3(TPB), 0, (const float *)sB, (const float *)nullptr,
+                      psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr, sA);
+            // HF: row + column pass of raw HF (sA) + split: HF, UHF -> psy, the mask input -> sB (raw MF is dead)
+            CE_LAUNCH(ctx, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
+                      psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, sB, (float *)nullptr);
         }
 
         // mask input: DiffPrecompute of HF + UHF (written by the HF split's epilogue into ba_s[1]), blurred with sigma 2.7 -

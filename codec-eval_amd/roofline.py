@@ -118,11 +118,9 @@ def butteraugli_bytes(b: Bucket, acc: Dict[str, float]):
             _add(acc, "ba_front", slots * n * (12 + 12))
         # SeparateFrequencies: row blur -> column blur fused with the split.  Planes are 4 B/px.
         _add(acc, "ba_blur_h33", slots * n * (12 + 12))
-        _add(acc, "ba_blur_v_lf", slots * n * (12 + 12 + 24))   # row-blurred + XYB in; raw MF + LF out
-        _add(acc, "ba_blur_h15", slots * n * (12 + 12))
-        _add(acc, "ba_blur_v_mf", slots * n * (12 + 8 + 12 + 8))  # row-blurred + raw MF X,Y in; MF x3 + raw HF x2 out
-        _add(acc, "ba_blur_h7", slots * n * (8 + 8))
-        _add(acc, "ba_blur_v_hf", slots * n * (8 + 8 + 16 + 4))  # row-blurred + raw HF in; HF x2 + UHF x2 + the mask input out
+        _add(acc, "ba_blur_v_lf", slots * n * (12 + 12 + 24))   # row-blurred + XYB in; LF + raw MF out
+        _add(acc, "ba_blur_hv_mf", slots * n * (12 + 12 + 8))   # raw MF in (row + column pass in one kernel); MF x3 + raw HF x2 out
+        _add(acc, "ba_blur_hv_hf", slots * n * (8 + 16 + 4))    # raw HF in; HF x2 + UHF x2 + the mask input out
         # the mask input's sigma-2.7 blur per image slot; the references' two mask-value planes
         _add(acc, "ba_blur_h13", slots * n * 8)
         _add(acc, "ba_blur_v13", slots * n * 8)

@@ -44,7 +44,7 @@ def test_step_bytes_names_are_launch_names():
     acc = rf.step_bytes([b], ["ssimulacra2", "dssim", "butteraugli", "psnr"], xyb_roundtrip=True)
     expected = {"ssim2_prep_u8", "ssim2_prep", "ssim2_hblur_L0", "ssim2_vblur_ssim_L0", "ssim2_hblur_L1-5", "ssim2_vblur_ssim_L1-5",
                 "dssim_create_u8", "dssim_create", "dssim_compare", "dssim_absdev", "ba_front_u8", "ba_subsample2x", "ba_front",
-                "ba_blur_h33", "ba_blur_v_lf", "ba_blur_h15", "ba_blur_v_mf", "ba_blur_h7", "ba_blur_v_hf", "ba_malta_l2",
+                "ba_blur_h33", "ba_blur_v_lf", "ba_blur_hv_mf", "ba_blur_hv_hf", "ba_malta_l2",
                 "ba_blur_h13", "ba_blur_v13", "ba_mask_vals", "psnr_sse", "xyb_roundtrip"}
     assert set(acc) == expected
     assert all(v > 0 for v in acc.values())
