@@ -448,7 +448,7 @@ __device__ __forceinline__ float mask_pre_one(float uhf0, float hf0, float uhf1,
     return sqrtf(kMul * fabsf(m) + bias) - sqrt_bias;
 }
 
-template <int LEN, int EPI, bool HV>
+template <int LEN, int EPI, bool HV, int TR = 64>
 __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict__ tmp, const float *__restrict__ xyb,
                                                          float *__restrict__ psy, geom g, blur_kernel bk, float inv_wsum,
                                                          uint32_t n_refs_used, uint32_t max_refs, uint32_t z0,
@@ -456,7 +456,8 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
 {
     constexpr int NP = EPI == EPI_HF ? 2 : 3;
     // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
-    constexpr int off = LEN / 2, TW = 64, TR = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
+    constexpr int off = LEN / 2, TW = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
+    static_assert(TR % 32 == 0, "four waves x 8 rows per part");
     // HV: the staged input is 4 or 8 columns wider on each side (>= off, and its rows load as aligned float4)
     constexpr int LEFT = off <= 4 ? 4 : 8, IW = HV ? TW + 2 * LEFT : TW;
     static_assert(!HV || off <= LEFT, "row-pass halo");
@@ -492,8 +493,13 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
             if (i < RAW * (IW / 4)) *reinterpret_cast<float4 *>((HV ? in_t : tile) + 4 * i) = pf[m];
         }
     };
-    // HV: the column of this thread is the same in every row it filters (TPB is a multiple of TW)
-    const float scale_x = (HV && col_live) ? border_scale<LEN>(bk, gx, (int)g.w, inv_wsum) : 0.0f;
+    // HV row pass: a thread filters four adjacent columns of a row from one aligned window of the input tile (NW float4 LDS
+    // reads for four outputs); its column group is the same in every row it visits (TPB is a multiple of TW / 4)
+    constexpr int S0 = LEFT - off, NW = (S0 + 3 + LEN + 3) / 4;
+    const int rc4 = 4 * ((int)threadIdx.x % (TW / 4));
+    float scale_x[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) scale_x[k] = (HV && x0 + rc4 + k < (int)g.w) ? border_scale<LEN>(bk, x0 + rc4 + k, (int)g.w, inv_wsum) : 0.0f;
     fetch(0);
     if (HV) {
         stash();
@@ -504,12 +510,24 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
         if (HV) {
             // row pass of every tile row: taps in ascending order, zero outside the image (x + 0.0f == x), border scale
 #pragma unroll 1
-            for (int i = threadIdx.x; i < RAW * TW; i += TPB) {
-                const float *src = in_t + (i / TW) * IW + c + LEFT - off;
-                float sum = 0.0f;
+            for (int u = threadIdx.x; u < RAW * (TW / 4); u += TPB) {
+                const int r = u / (TW / 4);
+                const float4 *src = reinterpret_cast<const float4 *>(in_t + r * IW + rc4);
+                float wnd[4 * NW];
 #pragma unroll
-                for (int j = 0; j < LEN; j++) sum += src[j] * bk.k[j];
-                tile[i] = sum * scale_x;  // scale_x = 0 right of the image: the column pass sees zeros there
+                for (int m = 0; m < NW; m++) {
+                    const float4 v = src[m];
+                    wnd[4 * m] = v.x, wnd[4 * m + 1] = v.y, wnd[4 * m + 2] = v.z, wnd[4 * m + 3] = v.w;
+                }
+                float out[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < LEN; j++) sum += wnd[S0 + k + j] * bk.k[j];
+                    out[k] = sum * scale_x[k];  // scale 0 right of the image: the column pass sees zeros there
+                }
+                *reinterpret_cast<float4 *>(tile + r * TW + rc4) = make_float4(out[0], out[1], out[2], out[3]);
             }
             __syncthreads();  // the tile is complete; the input tile may be overwritten
             if (q + 1 < NP) fetch(q + 1);
@@ -1288,9 +1306,25 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
             CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy,
                       g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
             // MF: row + column pass of raw MF (sB) + split: MF -> psy, raw HF -> sA (its old contents are dead)
+            // rows per block of the fused stages: 32 (default; 26 / 21 KB of LDS and ~100 / 56 registers: five blocks per CU)
+            // or 64 (CE_HV_ROWS=64: smaller halo, 45 / 38 KB, three or four blocks).  Measured (profiles/r02_experiments.md
+            // section 18): 32 rows 0.50 + 0.33 ms per step solo against 0.53 + 0.41; headline equal, 4K grid +3 %
+            static const int hv_rows = [] {
+                const char *e = std::getenv("CE_HV_ROWS");
+                return e && std::atoi(e) == 64 ? 64 : 32;
+            }();
+            const dim3 gvs32((g.w + 63) / 64, (g.h + 31) / 32, nz);
+            if (hv_rows == 32)
+                CE_LAUNCH(ctx, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sB,
+                          (const float *)nullptr, psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr, sA);
+            else
             CE_LAUNCH(ctx, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true>), gvs, dim3(TPB), 0, (const float *)sB, (const float *)nullptr,
                       psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr, sA);
             // HF: row + column pass of raw HF (sA) + split: HF, UHF -> psy, the mask input -> sB (raw MF is dead)
+            if (hv_rows == 32)
+                CE_LAUNCH(ctx, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
+                          (const float *)nullptr, psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, sB, (float *)nullptr);
+            else
             CE_LAUNCH(ctx, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
                       psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, sB, (float *)nullptr);
         }
