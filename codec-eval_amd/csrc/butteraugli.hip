@@ -220,38 +220,6 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
     }
 }
 
-// vertical: block = 64 columns x 32 rows; lane = column, wave w produces rows 8w .. 8w+7
-template <int LEN>
-__global__ __launch_bounds__(TPB) void k_ba_blur_v(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
-                                                   plane_sel so, blur_kernel bk, float inv_wsum, uint32_t n_refs_used,
-                                                   uint32_t max_refs, int by_slot, uint32_t z0)
-{
-    constexpr int off = LEN / 2, TW = 64, TR = 32, RAW = TR + LEN - 1;
-    __shared__ float tile[RAW * TW];
-    const uint32_t u = blockIdx.z / si.n + z0, k = blockIdx.z % si.n;
-    const uint32_t unit = by_slot ? slot_of(u, n_refs_used, max_refs) : u;
-    const float *p = in + ((size_t)unit * si.per_unit + si.first + k) * g.plane;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
-    for (int i = threadIdx.x; i < RAW * TW; i += TPB) {
-        const int r = i / TW, c = i % TW, gx = x0 + c, gy = y0 - off + r;
-        tile[i] = (gy >= 0 && gy < (int)g.h && gx < (int)g.w) ? p[(size_t)gy * g.pitch + gx] : 0.0f;
-    }
-    __syncthreads();
-    const int c = threadIdx.x & 63, w = threadIdx.x >> 6, gx = x0 + c, gy0 = y0 + 8 * w;
-    if (gx >= (int)g.w || gy0 >= (int)g.h) return;
-    float v[BW_OUT + LEN - 1];
-#pragma unroll
-    for (int j = 0; j < BW_OUT + LEN - 1; j++) v[j] = tile[(8 * w + j) * TW + c];
-    float *dst = out + ((size_t)unit * so.per_unit + so.first + k) * g.plane + (size_t)gy0 * g.pitch + gx;
-#pragma unroll
-    for (int o = 0; o < BW_OUT; o++) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
-        if (gy0 + o < (int)g.h) dst[(size_t)o * g.pitch] = sum * border_scale<LEN>(bk, gy0 + o, (int)g.h, inv_wsum);
-    }
-}
-
 // ---- OpsinDynamicsImage (pointwise part) ---------------------------------------------------------------
 __device__ __forceinline__ void opsin_absorbance(float in0, float in1, float in2, float &o0, float &o1, float &o2)
 {
@@ -433,7 +401,8 @@ __device__ __forceinline__ float maximum_clamp(float v, float maxval)
 // HBM.  A fused stage reads its raw band with a halo, so no stage may overwrite its own input: the raw bands live in
 // scratch planes (`aux`): LF stage -> raw MF -> aux_out;  MF stage: aux_in -> MF (psy), raw HF -> aux_out;  HF stage:
 // aux_in -> HF, UHF (psy), mask input.  (The 33-tap LF stage keeps its separate row pass: its halo would be half a tile.)
-enum { EPI_LF = 0, EPI_MF = 1, EPI_HF = 2 };
+//   EPI_MASK (1 plane per slot, sigma 2.7, HV): the mask input's blur, no pointwise stage: tmp[slot] -> aux_out[slot]
+enum { EPI_LF = 0, EPI_MF = 1, EPI_HF = 2, EPI_MASK = 3 };
 
 // MaskPsychoImage's input at one pixel: DiffPrecompute of (UHF + HF) of X and Y (pointwise on the FINAL band values)
 __device__ __forceinline__ float mask_pre_one(float uhf0, float hf0, float uhf1, float hf1)
@@ -454,7 +423,7 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                                                          uint32_t n_refs_used, uint32_t max_refs, uint32_t z0,
                                                          float *__restrict__ mask_in, float *__restrict__ aux_out)
 {
-    constexpr int NP = EPI == EPI_HF ? 2 : 3;
+    constexpr int NP = EPI == EPI_HF ? 2 : EPI == EPI_MASK ? 1 : 3;
     // 64 columns x 64 rows per block (two 8-row groups per thread): the halo of LEN - 1 rows is read once per 64 rows
     constexpr int off = LEN / 2, TW = 64, PARTS = TR / 32, RAW = TR + LEN - 1;
     static_assert(TR % 32 == 0, "four waves x 8 rows per part");
@@ -473,7 +442,8 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
     constexpr int NF = (RAW * (IW / 4) + TPB - 1) / TPB;
     float4 pf[NF];
     auto fetch = [&](int q) {
-        const float *p = tmp + ((size_t)slot * 3 + q) * g.plane;  // the row-blurred planes (HV: the raw band) of this slot
+        // the row-blurred planes (HV: the raw band) of this slot; the mask input is one plane per slot
+        const float *p = tmp + (EPI == EPI_MASK ? (size_t)slot : (size_t)slot * 3 + q) * g.plane;
 #pragma unroll
         for (int m = 0; m < NF; m++) {
             const int i = m * TPB + (int)threadIdx.x, r = i / (IW / 4), X = x0 - (HV ? LEFT : 0) + 4 * (i % (IW / 4)), Y = y0 - off + r;
@@ -595,6 +565,8 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                 const float scaler = __builtin_fmaf(suppress / __builtin_fmaf(hf1, hf1, suppress), one_minus_s, sv);
                 aux_out[ao] = scaler * hf0;  // raw HF, for the HF stage
                 aux_out[ao + pl] = hf1;
+            } else if (EPI == EPI_MASK) {
+                aux_out[(size_t)slot * pl + (size_t)(gy0 + o) * g.pitch + gx] = res[0][part][o];
             } else {
                 const float kRemoveHfRange = 1.5f, kAddHfRange = 0.132f, kRemoveUhfRange = 0.04f;
                 const float kMaxclampHf = 28.4691806922f, kMaxclampUhf = 5.19175294647f, kMulYHf = 2.155f, kMulYUhf = 2.69313763794f;
@@ -1124,32 +1096,6 @@ float inv_weight_sum(const blur_kernel &bk)
     return 1.0f / wsum;
 }
 
-template <int LEN>
-int launch_blur_len(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g, plane_sel si, plane_sel st, plane_sel so,
-                    const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot, uint32_t z0)
-{
-    const float inv = inv_weight_sum(bk);
-    const dim3 gh((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), units * si.n), gv((g.w + 63) / 64, (g.h + 31) / 32, units * si.n);
-    static const std::string name_h = "ba_blur_h" + std::to_string(LEN), name_v = "ba_blur_v" + std::to_string(LEN);
-    CE_LAUNCH(ctx, name_h.c_str(), k_ba_blur_h<LEN>, gh, dim3(TPB), 0, in, tmp, g, si, st, bk, inv, n_refs_used, mr, by_slot, z0);
-    CE_LAUNCH(ctx, name_v.c_str(), k_ba_blur_v<LEN>, gv, dim3(TPB), 0, (const float *)tmp, out, g, st, so, bk, inv, n_refs_used, mr, by_slot, z0);
-    return CE_OK;
-}
-
-// in[si] -> (row pass) tmp[st] -> (column pass) out[so]
-int launch_blur(ce_ctx *ctx, const float *in, float *tmp, float *out, geom g, plane_sel si, plane_sel st, plane_sel so,
-                const blur_kernel &bk, uint32_t units, uint32_t n_refs_used, uint32_t mr, int by_slot, uint32_t z0)
-{
-    switch (bk.len) {
-        case 7: return launch_blur_len<7>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
-        case 13: return launch_blur_len<13>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
-        case 15: return launch_blur_len<15>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
-        case 33: return launch_blur_len<33>(ctx, in, tmp, out, g, si, st, so, bk, units, n_refs_used, mr, by_slot, z0);
-    }
-    ctx->err = "unexpected blur kernel length";
-    return CE_ERR_BACKEND;
-}
-
 malta_params make_malta(double w_0gt1, double w_0lt1, double norm1, bool lf)
 {
     const double len = 3.75, mulli = lf ? 0.611612573796 : 0.39905817637;
@@ -1333,8 +1279,15 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         // per image slot (the references' once per reference; cached with the PsychoImage for reference handles), into
         // the level's own per-slot planes; then the
         // references' mask values (FuzzyErosion + the two mask curves), also once per reference
-        const plane_sel s1{1, 0, 1};
-        if ((rc = launch_blur(ctx, b->ba_s[1], b->ba_s[0], b->ba_mask[l], g, s1, s1, s1, kMask, nz, n_refs_used, mr, 1, z0)) != CE_OK) return rc;
+        {
+            if (kMask.len != 13) {
+                ctx->err = "unexpected blur kernel length";
+                return CE_ERR_BACKEND;
+            }
+            const dim3 gm((g.w + 63) / 64, (g.h + 31) / 32, nz);
+            CE_LAUNCH(ctx, "ba_blur_hv_mask", (k_ba_blur_v_split<13, EPI_MASK, true, 32>), gm, dim3(TPB), 0, (const float *)b->ba_s[1],
+                      (const float *)nullptr, psy, g, kMask, inv_weight_sum(kMask), n_refs_used, mr, z0, (float *)nullptr, b->ba_mask[l]);
+        }
         if (!cached)
             CE_LAUNCH(ctx, "ba_mask_vals", k_ba_mask_vals, G(n_refs_used), dim3(TPB), 0, (const float *)b->ba_mask[l], b->ba_mask_vals[l], g);
 

@@ -122,8 +122,7 @@ def butteraugli_bytes(b: Bucket, acc: Dict[str, float]):
         _add(acc, "ba_blur_hv_mf", slots * n * (12 + 12 + 8))   # raw MF in (row + column pass in one kernel); MF x3 + raw HF x2 out
         _add(acc, "ba_blur_hv_hf", slots * n * (8 + 16 + 4))    # raw HF in; HF x2 + UHF x2 + the mask input out
         # the mask input's sigma-2.7 blur per image slot; the references' two mask-value planes
-        _add(acc, "ba_blur_h13", slots * n * 8)
-        _add(acc, "ba_blur_v13", slots * n * 8)
+        _add(acc, "ba_blur_hv_mask", slots * n * 8)
         _add(acc, "ba_mask_vals", R * n * (4 + 8))
         # per pair: Malta + L2 terms + CombineChannelsToDiffmap read the ten PsychoImage planes and the blurred mask plane
         # of both images and the reference's two mask-value planes (the AC / DC triples stay in registers); the

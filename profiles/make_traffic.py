@@ -37,7 +37,7 @@ SHORT = [
     (r"k_dssim_avg", "dssim_avg"), (r"k_dssim_absdev", "dssim_absdev"), (r"k_dssim_finalize_pairs", "dssim_finalize"),
     (r"k_ba_front<true>", "ba_front_u8"), (r"k_ba_front<false>", "ba_front"), (r"k_ba_subsample2x_u8", "ba_subsample2x"),
     (r"k_ba_blur_h<(\d+)>", "ba_blur_h{}"), (r"k_ba_blur_v<(\d+)>", "ba_blur_v{}"),
-    (r"k_ba_blur_v_split<33", "ba_blur_v_lf"), (r"k_ba_blur_v_split<15, *1, *true", "ba_blur_hv_mf"), (r"k_ba_blur_v_split<7, *2, *true", "ba_blur_hv_hf"),
+    (r"k_ba_blur_v_split<13", "ba_blur_hv_mask"), (r"k_ba_blur_v_split<33", "ba_blur_v_lf"), (r"k_ba_blur_v_split<15, *1, *true", "ba_blur_hv_mf"), (r"k_ba_blur_v_split<7, *2, *true", "ba_blur_hv_hf"),
     (r"k_ba_blur_v_split<15", "ba_blur_v_mf"), (r"k_ba_blur_v_split<7", "ba_blur_v_hf"),
     (r"k_ba_malta_l2_xy", "ba_malta_l2"), (r"k_ba_mask_pre", "ba_mask_pre"), (r"k_ba_mask_vals", "ba_mask_vals"), (r"k_ba_mask_combine", "ba_mask_combine"),
     (r"k_ba_final", "ba_final"), (r"k_ba_score", "ba_score"), (r"k_psnr_sse", "psnr_sse"), (r"k_psnr_clear", "psnr_clear"),
