@@ -53,38 +53,6 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, ui
     return z < n_refs_used ? z : max_refs + (z - n_refs_used);
 }
 
-// ---- SubSample2x straight from the u8 slabs: out(x/2, y/2) += 0.25 * lin(x, y) in raster order; odd edges doubled ----
-__global__ __launch_bounds__(TPB) void k_ba_subsample2x_u8(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
-                                                           const float *__restrict__ lut, float *__restrict__ out, geom gi, geom g,
-                                                           size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
-{
-    __shared__ float s_lut[256];
-    s_lut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
-    const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);  // z0 > 0: the references' PsychoImage is cached
-    const uint8_t *src = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
-    BA_XY;
-    float acc[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (uint32_t dy = 0; dy < 2; dy++)
-#pragma unroll
-        for (uint32_t dx = 0; dx < 2; dx++) {
-            const uint32_t ix = 2 * x + dx, iy = 2 * y + dy;
-            if (ix < gi.w && iy < gi.h) {
-                const uint8_t *px = src + ((size_t)iy * gi.w + ix) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; c++) acc[c] += 0.25f * s_lut[px[c]];
-            }
-        }
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float v = acc[c];
-        if ((gi.w & 1) && x == g.w - 1) v *= 2.0f;
-        if ((gi.h & 1) && y == g.h - 1) v *= 2.0f;
-        out[((size_t)slot * 3 + c) * g.plane + o] = v;
-    }
-}
-
 // ---- separable blurs ------------------------------------------------------------------------------------
 // unit stride `us` planes per unit; planes [first, first+n) of each unit are processed; z = unit * n + k
 struct plane_sel {
@@ -260,9 +228,12 @@ __device__ __forceinline__ float gamma_f(float v)
 // 2-pixel halo in LDS -> the 5-tap sigma-1.2 blur (mirrored at the image border, both passes in LDS) ->
 // OpsinDynamicsImage -> XYB planes.  Only XYB is written (12 B/px); nothing else of this stage touches HBM.
 constexpr int FT = 32, FR = FT + 4;
-template <bool FROM_U8>
+// HALF: the half-resolution level - its linear RGB is the 2x2 average of the full-resolution image's (Subsample2x: the
+// four quarter-weighted samples added in row-major order, the last odd row / column doubled), formed here from the u8
+// source instead of in a pass of its own; gi = the full-resolution geometry.
+template <bool HALF>
 __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
-                                                  const float *__restrict__ lut, const float *__restrict__ lin_in,
+                                                  const float *__restrict__ lut, geom gi,
                                                   float *__restrict__ xyb, geom g, float w0, float w1, float w2,
                                                   float intensity_target, size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs,
                                                   uint32_t z0)
@@ -270,43 +241,80 @@ __global__ __launch_bounds__(TPB) void k_ba_front(const uint8_t *__restrict__ re
     __shared__ float L[3][FR * FR];   // linear, region = tile + 2
     __shared__ float H[3][FR * FT];   // row-blurred: FR rows x FT columns
     __shared__ float s_lut[256];
-    if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
     const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);
     const int w = (int)g.w, h = (int)g.h, x0 = blockIdx.x * FT, y0 = blockIdx.y * FT, gx0 = x0 - 2, gy0 = y0 - 2;
-    const uint8_t *src8 = nullptr;
-    if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
-    const float *srcf = lin_in + (size_t)slot * 3 * g.plane;
+    const uint8_t *src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
+    const int W8 = HALF ? (int)gi.w : w, H8 = HALF ? (int)gi.h : h;  // the u8 image
     __syncthreads();
     const bool interior = gx0 >= 0 && gy0 >= 0 && gx0 + FR <= w && gy0 + FR <= h;
-    if (FROM_U8 && interior) {
-        // four pixels (12 bytes, any alignment) per task from four aligned dwords; nine tasks per row of the region
+    // four u8 pixels (12 bytes, any alignment) from four aligned dwords
+    auto load12 = [&](const uint8_t *p, uint32_t &v0, uint32_t &v1, uint32_t &v2) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], sh = (uint32_t)(a & 3);
+        v0 = __builtin_amdgcn_alignbyte(d1, d0, sh), v1 = __builtin_amdgcn_alignbyte(d2, d1, sh), v2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    };
+    if (!HALF && interior) {
+        // four pixels per task; nine tasks per row of the region
         for (int i = threadIdx.x; i < FR * (FR / 4); i += TPB) {
             const int ly = i / (FR / 4), lx = 4 * (i % (FR / 4));
-            const uintptr_t a = reinterpret_cast<uintptr_t>(src8 + ((size_t)(gy0 + ly) * w + gx0 + lx) * 3);
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], sh = (uint32_t)(a & 3);
-            const uint32_t v0 = __builtin_amdgcn_alignbyte(d1, d0, sh), v1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                           v2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            uint32_t v0, v1, v2;
+            load12(src8 + ((size_t)(gy0 + ly) * w + gx0 + lx) * 3, v0, v1, v2);
             const int o = ly * FR + lx;
             L[0][o] = s_lut[v0 & 255u], L[1][o] = s_lut[(v0 >> 8) & 255u], L[2][o] = s_lut[(v0 >> 16) & 255u];
             L[0][o + 1] = s_lut[v0 >> 24], L[1][o + 1] = s_lut[v1 & 255u], L[2][o + 1] = s_lut[(v1 >> 8) & 255u];
             L[0][o + 2] = s_lut[(v1 >> 16) & 255u], L[1][o + 2] = s_lut[v1 >> 24], L[2][o + 2] = s_lut[v2 & 255u];
             L[0][o + 3] = s_lut[(v2 >> 8) & 255u], L[1][o + 3] = s_lut[(v2 >> 16) & 255u], L[2][o + 3] = s_lut[v2 >> 24];
         }
+    } else if (HALF && interior && 2 * (gx0 + FR) <= W8 && 2 * (gy0 + FR) <= H8) {
+        // two half-resolution elements (2 x 4 u8 pixels) per task: ((0 + q00) + q01) + q10) + q11, q = 0.25 * linear
+        for (int i = threadIdx.x; i < FR * (FR / 2); i += TPB) {
+            const int ly = i / (FR / 2), lx = 2 * (i % (FR / 2));
+            uint32_t a0, a1, a2, b0, b1, b2;
+            const uint8_t *p = src8 + ((size_t)(2 * (gy0 + ly)) * W8 + 2 * (gx0 + lx)) * 3;
+            load12(p, a0, a1, a2);
+            load12(p + (size_t)W8 * 3, b0, b1, b2);
+            const int o = ly * FR + lx;
+            // row pixels: p0 = (v0.b0, v0.b1, v0.b2), p1 = (v0.b3, v1.b0, v1.b1), p2 = (v1.b2, v1.b3, v2.b0), p3 = (v2.b1, v2.b2, v2.b3)
+#define CE_Q(v) (0.25f * s_lut[(v)])
+            L[0][o] = ((0.0f + CE_Q(a0 & 255u)) + CE_Q(a0 >> 24)) + CE_Q(b0 & 255u) + CE_Q(b0 >> 24);
+            L[1][o] = ((0.0f + CE_Q((a0 >> 8) & 255u)) + CE_Q(a1 & 255u)) + CE_Q((b0 >> 8) & 255u) + CE_Q(b1 & 255u);
+            L[2][o] = ((0.0f + CE_Q((a0 >> 16) & 255u)) + CE_Q((a1 >> 8) & 255u)) + CE_Q((b0 >> 16) & 255u) + CE_Q((b1 >> 8) & 255u);
+            L[0][o + 1] = ((0.0f + CE_Q((a1 >> 16) & 255u)) + CE_Q((a2 >> 8) & 255u)) + CE_Q((b1 >> 16) & 255u) + CE_Q((b2 >> 8) & 255u);
+            L[1][o + 1] = ((0.0f + CE_Q(a1 >> 24)) + CE_Q((a2 >> 16) & 255u)) + CE_Q(b1 >> 24) + CE_Q((b2 >> 16) & 255u);
+            L[2][o + 1] = ((0.0f + CE_Q(a2 & 255u)) + CE_Q(a2 >> 24)) + CE_Q(b2 & 255u) + CE_Q(b2 >> 24);
+#undef CE_Q
+        }
     } else
     for (int i = threadIdx.x; i < FR * FR; i += TPB) {
         const int lx = i % FR, ly = i / FR, X = gx0 + lx, Y = gy0 + ly;
         if (X >= 0 && X < w && Y >= 0 && Y < h) {
-            if (FROM_U8) {
+            if (!HALF) {
                 const uint8_t *px = src8 + ((size_t)Y * w + X) * 3;
                 L[0][i] = s_lut[px[0]];
                 L[1][i] = s_lut[px[1]];
                 L[2][i] = s_lut[px[2]];
             } else {
-                const size_t o = (size_t)Y * g.pitch + X;
-                L[0][i] = srcf[o];
-                L[1][i] = srcf[o + g.plane];
-                L[2][i] = srcf[o + 2 * g.plane];
+                float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+                    for (int dx = 0; dx < 2; dx++) {
+                        const int ix = 2 * X + dx, iy = 2 * Y + dy;
+                        if (ix < W8 && iy < H8) {
+                            const uint8_t *px = src8 + ((size_t)iy * W8 + ix) * 3;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) acc[c] += 0.25f * s_lut[px[c]];
+                        }
+                    }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float v = acc[c];
+                    if ((W8 & 1) && X == w - 1) v *= 2.0f;
+                    if ((H8 & 1) && Y == h - 1) v *= 2.0f;
+                    L[c][i] = v;
+                }
             }
         }
     }
@@ -1123,14 +1131,13 @@ int ce_butteraugli_div_sweep(ce_ctx *ctx, uint64_t seed, uint64_t count, uint64_
 void ce_butteraugli_free(ce_batch *b)
 {
     for (int l = 0; l < 2; l++) {
-        hipFree(b->ba_lin[l]);
         hipFree(b->ba_psy[l]);
         hipFree(b->ba_diff[l]);
         hipFree(b->ba_mask[l]);
         hipFree(b->ba_mask_vals[l]);
         b->ba_mask_vals[l] = nullptr;
         ce_free_xcd_list(&b->ba_work[l]);
-        b->ba_lin[l] = b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
+        b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
     }
     for (auto &p : b->ba_s) hipFree(p), p = nullptr;
     hipFree(b->ba_blk_max);
@@ -1157,7 +1164,6 @@ static int ba_allocate(ce_batch *b)
     b->ba_levels = (b->ba[1].w >= 8 && b->ba[1].h >= 8) ? 2 : 1;
     const size_t slots = (size_t)b->max_refs + b->max_pairs, P = b->max_pairs, p0 = b->ba[0].plane;
     for (int l = 0; l < b->ba_levels; l++) {
-        if (l == 1) CE_HIP(ctx, hipMalloc(&b->ba_lin[l], slots * 3 * b->ba[l].plane * sizeof(float)));  // level 0 reads u8
         CE_HIP(ctx, hipMalloc(&b->ba_psy[l], slots * PSY * b->ba[l].plane * sizeof(float)));
         if (l == 1) CE_HIP(ctx, hipMalloc(&b->ba_diff[l], P * b->ba[l].plane * sizeof(float)));  // the full-resolution diffmap is never stored
     }
@@ -1222,19 +1228,17 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         const geom g{d.w, d.h, d.pitch, d.plane};
         const dim3 gx((d.w + 63) / 64, (d.h + 3) / 4, 1);
         auto G = [&](uint32_t z) { return dim3(gx.x, gx.y, z); };
-        float *lin = b->ba_lin[l], *psy = b->ba_psy[l], *sA = b->ba_s[0], *sC = b->ba_s[2];
+        float *psy = b->ba_psy[l], *sA = b->ba_s[0], *sC = b->ba_s[2];
         // ---- per image slot: PsychoImage ----
         const plane_sel s3{3, 0, 3};
         const dim3 ft((d.w + FT - 1) / FT, (d.h + FT - 1) / FT, nz);
         if (l == 0) {
-            CE_LAUNCH(ctx, "ba_front_u8", k_ba_front<true>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
-                      (const float *)nullptr, sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
+            CE_LAUNCH(ctx, "ba_front_u8", k_ba_front<false>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, g, sC, g, w0, w1, w2,
+                      intensity_target, b->img_bytes, n_refs_used, mr, z0);
         } else {
             const auto &pd = b->ba[0];
-            CE_LAUNCH(ctx, "ba_subsample2x", k_ba_subsample2x_u8, G(nz), dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, lin,
-                      geom{pd.w, pd.h, pd.pitch, pd.plane}, g, b->img_bytes, n_refs_used, mr, z0);
-            CE_LAUNCH(ctx, "ba_front", k_ba_front<false>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, (const float *)lin,
-                      sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
+            CE_LAUNCH(ctx, "ba_front_half", k_ba_front<true>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
+                      geom{pd.w, pd.h, pd.pitch, pd.plane}, sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
         }
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
         // SeparateFrequencies: row blur of a band, then column blur fused with the pointwise split (k_ba_blur_v_split)

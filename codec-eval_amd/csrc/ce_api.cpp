@@ -849,8 +849,8 @@ size_t ce_estimate_batch_bytes(uint32_t w, uint32_t h, uint32_t n_refs, uint32_t
         bytes += px * (6.0 * slots + 48.0 * n_refs + 16.0 * pairs);
         allocations += 24;
     }
-    if (metric_mask & CE_METRIC_BUTTERAUGLI) {  // half-res linear 3, PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; mask values 10 per reference; half-resolution diffmap 1 per pair
-        bytes += px * (94.0 * slots + 10.0 * n_refs + 1.0 * pairs);
+    if (metric_mask & CE_METRIC_BUTTERAUGLI) {  // PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; mask values 10 per reference; half-resolution diffmap 1 per pair
+        bytes += px * (91.0 * slots + 10.0 * n_refs + 1.0 * pairs);
         allocations += 20;
     }
     if (metric_mask & CE_METRIC_PSNR) bytes += 8.0 * pairs;

@@ -169,7 +169,6 @@ struct ce_batch {
     struct ba_level { uint32_t w, h, pitch; size_t plane; };
     ba_level ba[2];
     int ba_levels = 0;
-    float *ba_lin[2] = {};    // [slot][3][plane_l]
     float *ba_psy[2] = {};    // [slot][10][plane_l]  PsychoImage
     float *ba_diff[2] = {};   // [pair][plane_1]      the half-resolution diffmap ([1]; the full-resolution one is reduced in registers)
     float *ba_mask[2] = {};   // [slot][plane_l]      blurred mask input (DiffPrecompute of HF + UHF, sigma 2.7)

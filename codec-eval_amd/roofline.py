@@ -114,8 +114,7 @@ def butteraugli_bytes(b: Bucket, acc: Dict[str, float]):
         if l == 0:
             _add(acc, "ba_front_u8", slots * n * (3 + 12))  # u8 in, XYB out (sigma-1.2 blur + opsin dynamics in LDS)
         else:
-            _add(acc, "ba_subsample2x", slots * (3 * b.px + 12 * n))
-            _add(acc, "ba_front", slots * n * (12 + 12))
+            _add(acc, "ba_front_half", slots * (3 * b.px + 12 * n))  # the full-resolution u8 in (2x2 averaged on the fly), XYB out
         # SeparateFrequencies: row blur -> column blur fused with the split.  Planes are 4 B/px.
         _add(acc, "ba_blur_h33", slots * n * (12 + 12))
         _add(acc, "ba_blur_v_lf", slots * n * (12 + 12 + 24))   # row-blurred + XYB in; LF + raw MF out

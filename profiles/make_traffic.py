@@ -35,7 +35,7 @@ SHORT = [
     (r"k_ssim2_prep<true>", "ssim2_prep_u8"), (r"k_ssim2_prep<false>", "ssim2_prep"), (r"k_ssim2_finalize", "ssim2_finalize"),
     (r"k_dssim_create<true>", "dssim_create_u8"), (r"k_dssim_create<false>", "dssim_create"), (r"k_dssim_compare", "dssim_compare"),
     (r"k_dssim_avg", "dssim_avg"), (r"k_dssim_absdev", "dssim_absdev"), (r"k_dssim_finalize_pairs", "dssim_finalize"),
-    (r"k_ba_front<true>", "ba_front_u8"), (r"k_ba_front<false>", "ba_front"), (r"k_ba_subsample2x_u8", "ba_subsample2x"),
+    (r"k_ba_front<false>", "ba_front_u8"), (r"k_ba_front<true>", "ba_front_half"), (r"k_ba_subsample2x_u8", "ba_subsample2x"),
     (r"k_ba_blur_h<(\d+)>", "ba_blur_h{}"), (r"k_ba_blur_v<(\d+)>", "ba_blur_v{}"),
     (r"k_ba_blur_v_split<13", "ba_blur_hv_mask"), (r"k_ba_blur_v_split<33", "ba_blur_v_lf"), (r"k_ba_blur_v_split<15, *1, *true", "ba_blur_hv_mf"), (r"k_ba_blur_v_split<7, *2, *true", "ba_blur_hv_hf"),
     (r"k_ba_blur_v_split<15", "ba_blur_v_mf"), (r"k_ba_blur_v_split<7", "ba_blur_v_hf"),

@@ -43,7 +43,7 @@ def test_step_bytes_names_are_launch_names():
     b = rf.Bucket(512, 512, 2, 6)
     acc = rf.step_bytes([b], ["ssimulacra2", "dssim", "butteraugli", "psnr"], xyb_roundtrip=True)
     expected = {"ssim2_prep_u8", "ssim2_prep", "ssim2_hblur_L0", "ssim2_vblur_ssim_L0", "ssim2_hblur_L1-5", "ssim2_vblur_ssim_L1-5",
-                "dssim_create_u8", "dssim_create", "dssim_compare", "dssim_absdev", "ba_front_u8", "ba_subsample2x", "ba_front",
+                "dssim_create_u8", "dssim_create", "dssim_compare", "dssim_absdev", "ba_front_u8", "ba_front_half",
                 "ba_blur_h33", "ba_blur_v_lf", "ba_blur_hv_mf", "ba_blur_hv_hf", "ba_malta_l2",
                 "ba_blur_hv_mask", "ba_mask_vals", "psnr_sse", "xyb_roundtrip"}
     assert set(acc) == expected
