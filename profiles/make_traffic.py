@@ -84,8 +84,25 @@ def main():
         with open(os.path.join(HERE, f"{stats_tag}_kernel_stats.csv"), "w", newline="") as fo:
             w = csv.writer(fo)
             w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            # one row per LAUNCH NAME (what bench.py / ce_prof_* call the kernel); a launch name that covers several
+            # template instances (ba_malta_l2: the full- and the half-resolution level) gets one merged row - the average
+            # bench.py's roofline.avg_launch_ms is compared with - followed by a row per instance
+            groups = collections.OrderedDict()
             for r in rows:
-                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+                groups.setdefault(short(r["Name"]), []).append(r)
+            for name, rs in groups.items():
+                if len(rs) == 1:
+                    r = rs[0]
+                    w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+                    continue
+                calls = sum(int(r["Calls"]) for r in rs)
+                total = sum(int(r["TotalDurationNs"]) for r in rs)
+                w.writerow([name, calls, total, f"{total / calls:.6f}", f"{sum(float(r['Percentage']) for r in rs):.2f}",
+                            min(int(r["MinNs"]) for r in rs), max(int(r["MaxNs"]) for r in rs)])
+                for r in rs:
+                    inst = re.search(r"<([^>]*)>", r["Name"])
+                    w.writerow([f"{name} [instance <{inst.group(1) if inst else '?'}>]", r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                r["Percentage"], r["MinNs"], r["MaxNs"]])
     side = json.load(open(sidecar))
     rf = importlib.import_module("codec-eval_amd.roofline")
     alg = rf.step_bytes([rf.Bucket(side["width"], side["height"], side["n_refs"], side["n_pairs"])], side["metrics"], side["xyb_roundtrip"])
