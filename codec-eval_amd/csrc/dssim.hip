@@ -114,28 +114,31 @@ constexpr int DT = 32, DR = DT + 8;
     _Pragma("unroll 1") for (int i = threadIdx.x, lx = i % (R), ly = i / (R); i < (R) * (R); i += TPB, lx = i % (R), ly = i / (R)) \
         if (lx >= (M) && lx < (R) - (M) && ly >= (M) && ly < (R) - (M))
 
-// FULL = a reference slot (img, mu, sq); otherwise a distorted image (img only: S1, S2 and the img store)
-template <bool IN, bool FULL>
+// FULL = a reference slot (img, mu, sq; region RW = tile + 8); otherwise a distorted image (img only: S1, S2 and the img
+// store; its region is the tile + 4 the two chroma passes need - a quarter less L*a*b* work than the reference's 40 x 40)
+template <bool IN, bool FULL, int RW>
 __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], float *__restrict__ img, float *__restrict__ mu,
                                                     float *__restrict__ sq, const lvl_geom &g, uint32_t slot, int x0, int y0)
 {
-    const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 4, gy0 = y0 - 4;
+    constexpr int HL = (RW - DT) / 2;
+    static_assert(FULL ? HL == 4 : HL == 2, "halo");
+    const int w = (int)g.w, h = (int)g.h, gx0 = x0 - HL, gy0 = y0 - HL;
     auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
     // Six LDS planes are enough (38 KB, four blocks per CU instead of two): planes are reused as soon as their
     // contents are dead, and mu / sq are produced one after the other through the same three planes.
     // S1: chroma pre-blur pass 1 (margin 1): P1,P2 -> P3,P4
-    CE_MARGIN_LOOP(DR, 1, i, lx, ly) {
+    CE_MARGIN_LOOP(RW, 1, i, lx, ly) {
         if (IN || inside(lx, ly)) {
-            P[3][i] = pass3x3<DR, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<DR, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
+            P[3][i] = pass3x3<RW, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<RW, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
     // S2: chroma pre-blur pass 2 (margin 2): P3,P4 -> P1,P2 (their old contents are dead) ; img = (P0, P1, P2)
-    CE_MARGIN_LOOP(DR, 2, i, lx, ly) {
+    CE_MARGIN_LOOP(RW, 2, i, lx, ly) {
         if (IN || inside(lx, ly)) {
-            P[1][i] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
-            P[2][i] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
+            P[1][i] = pass3x3<RW, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
+            P[2][i] = pass3x3<RW, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
@@ -144,7 +147,7 @@ __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], floa
             const int tx = i % DT, ty = i / DT, X = x0 + tx, Y = y0 + ty;
             if (IN || (X < w && Y < h)) {
                 const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-                const int li = (ty + 4) * DR + tx + 4;
+                const int li = (ty + HL) * RW + tx + HL;
                 img[o] = P[0][li];
                 img[o + g.plane] = P[1][li];
                 img[o + 2 * g.plane] = P[2][li];
@@ -153,46 +156,46 @@ __device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], floa
         return;
     }
     // S3a: first pass of mu (margin 3): img -> P3,P4,P5
-    CE_MARGIN_LOOP(DR, 3, i, lx, ly) {
+    CE_MARGIN_LOOP(RW, 3, i, lx, ly) {
         if (IN || inside(lx, ly)) {
-            P[3][i] = pass3x3<DR, false, IN>(P[0], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<DR, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
-            P[5][i] = pass3x3<DR, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
+            P[3][i] = pass3x3<RW, false, IN>(P[0], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<RW, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
+            P[5][i] = pass3x3<RW, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
     // S4a: second pass of mu on the tile itself; write img and mu
     for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-        const int tx = i % DT, ty = i / DT, lx = tx + 4, ly = ty + 4, X = x0 + tx, Y = y0 + ty;
+        const int tx = i % DT, ty = i / DT, lx = tx + HL, ly = ty + HL, X = x0 + tx, Y = y0 + ty;
         if (IN || (X < w && Y < h)) {
             const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-            const int li = ly * DR + lx;
+            const int li = ly * RW + lx;
             img[o] = P[0][li];
             img[o + g.plane] = P[1][li];
             img[o + 2 * g.plane] = P[2][li];
-            mu[o] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
-            mu[o + g.plane] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
-            mu[o + 2 * g.plane] = pass3x3<DR, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
+            mu[o] = pass3x3<RW, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
+            mu[o + g.plane] = pass3x3<RW, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
+            mu[o + 2 * g.plane] = pass3x3<RW, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
     // S3b: first pass of sq = blur(img * img): img -> P3,P4,P5
-    CE_MARGIN_LOOP(DR, 3, i, lx, ly) {
+    CE_MARGIN_LOOP(RW, 3, i, lx, ly) {
         if (IN || inside(lx, ly)) {
-            P[3][i] = pass3x3<DR, true, IN>(P[0], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<DR, true, IN>(P[1], lx, ly, gx0, gy0, w, h);
-            P[5][i] = pass3x3<DR, true, IN>(P[2], lx, ly, gx0, gy0, w, h);
+            P[3][i] = pass3x3<RW, true, IN>(P[0], lx, ly, gx0, gy0, w, h);
+            P[4][i] = pass3x3<RW, true, IN>(P[1], lx, ly, gx0, gy0, w, h);
+            P[5][i] = pass3x3<RW, true, IN>(P[2], lx, ly, gx0, gy0, w, h);
         }
     }
     __syncthreads();
     // S4b: second pass of sq; write sq
     for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-        const int tx = i % DT, ty = i / DT, lx = tx + 4, ly = ty + 4, X = x0 + tx, Y = y0 + ty;
+        const int tx = i % DT, ty = i / DT, lx = tx + HL, ly = ty + HL, X = x0 + tx, Y = y0 + ty;
         if (IN || (X < w && Y < h)) {
             const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-            sq[o] = pass3x3<DR, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
-            sq[o + g.plane] = pass3x3<DR, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
-            sq[o + 2 * g.plane] = pass3x3<DR, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
+            sq[o] = pass3x3<RW, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
+            sq[o + g.plane] = pass3x3<RW, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
+            sq[o + 2 * g.plane] = pass3x3<RW, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
         }
     }
 }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
     const bool is_ref = z < n_refs_used;
     const uint32_t oslot = is_ref ? z : z - n_refs_used;
     const int w = (int)g.w, h = (int)g.h;
-    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT, gx0 = x0 - 4, gy0 = y0 - 4;
+    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT;
     const uint8_t *src8 = nullptr;
     if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
     const float *srcf = lin_in + (size_t)slot * 3 * g.plane;
@@ -234,14 +237,6 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
             b = srcf[o + 2 * g.plane];
         }
     };
-    // S0: L*a*b* of the clamped region
-    for (int i = threadIdx.x; i < DR * DR; i += TPB) {
-        const int lx = i % DR, ly = i / DR;
-        const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
-        float r, gg, b;
-        load_rgb(X, Y, r, gg, b);
-        rgb_to_lab(r, gg, b, P[0][i], P[1][i], P[2][i]);
-    }
     // next level: (a + b + c + d) * 0.25 over the tile's own 2x2 quads, floor sizes (odd last row/column dropped)
     if (has_next) {
         const int ox = x0 / 2 + (threadIdx.x & 15), oy = y0 / 2 + (threadIdx.x >> 4);
@@ -254,21 +249,30 @@ __global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict_
                 lin_out[((size_t)slot * 3 + c) * gn.plane + (size_t)oy * gn.pitch + ox] = (q[0][c] + q[1][c] + q[2][c] + q[3][c]) * 0.25f;
         }
     }
-    __syncthreads();
-    // S1..S4 (two chroma pre-blur passes, two passes each for mu and sq, stores): a block whose 40x40 region is
-    // wholly inside the image takes the variant without clamping or bounds tests
-    const bool in = gx0 >= 0 && gy0 >= 0 && gx0 + DR <= w && gy0 + DR <= h;
-    if (is_ref) {
-        if (in)
-            dssim_create_stages<true, true>(P, rimg, rmu, rsq, g, oslot, x0, y0);
+    // S0: L*a*b* of the clamped region (tile + 4 for a reference, tile + 2 for a distorted image), then S1..S4: a block
+    // whose region is wholly inside the image takes the variant without clamping or bounds tests
+    auto region = [&](auto rw_tag, auto full_tag, float *oimg, float *omu, float *osq) {
+        constexpr int RW = decltype(rw_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int HL = (RW - DT) / 2;
+        const int gx0 = x0 - HL, gy0 = y0 - HL;
+        for (int i = threadIdx.x; i < RW * RW; i += TPB) {
+            const int lx = i % RW, ly = i / RW;
+            const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
+            float r, gg, b;
+            load_rgb(X, Y, r, gg, b);
+            rgb_to_lab(r, gg, b, P[0][i], P[1][i], P[2][i]);
+        }
+        __syncthreads();
+        if (gx0 >= 0 && gy0 >= 0 && gx0 + RW <= w && gy0 + RW <= h)
+            dssim_create_stages<true, FULL, RW>(P, oimg, omu, osq, g, oslot, x0, y0);
         else
-            dssim_create_stages<false, true>(P, rimg, rmu, rsq, g, oslot, x0, y0);
-    } else {
-        if (in)
-            dssim_create_stages<true, false>(P, img, nullptr, nullptr, g, oslot, x0, y0);
-        else
-            dssim_create_stages<false, false>(P, img, nullptr, nullptr, g, oslot, x0, y0);
-    }
+            dssim_create_stages<false, FULL, RW>(P, oimg, omu, osq, g, oslot, x0, y0);
+    };
+    if (is_ref)
+        region(std::integral_constant<int, DR>{}, std::true_type{}, rimg, rmu, rsq);
+    else
+        region(std::integral_constant<int, DT + 4>{}, std::false_type{}, img, nullptr, nullptr);
 }
 
 __device__ __forceinline__ double block_sum(double v, double *s_red)
