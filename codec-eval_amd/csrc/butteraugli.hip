@@ -3,18 +3,21 @@
 // codec-compare bins).  Restates libjxl's butteraugli.cc pipeline stage by stage, in the same f32
 // operation order as the CPU restatement (oracle/butteraugli.c):
 //
-//   per image slot and resolution level (full, 2x-subsampled) — the "PsychoImage", built once per
+//   per image slot and resolution level (2x-subsampled first, then full) — the "PsychoImage", built once per
 //   reference, not once per pair:
-//     sRGB u8 -> linear -> blur sigma 1.2 (5-tap, mirrored) -> OpsinDynamicsImage -> XYB
-//     -> LF = blur 7.156 ; MF = blur 3.225 of (XYB - LF) ; HF = blur 1.564 of the rest ; UHF = rest,
-//        with the range shaping of SeparateFrequencies -> 10 planes
-//   per pair and level:
-//     Malta line filters (UHF, HF, MF; X and Y), asymmetric L2 (HF), L2 (MF), L2 (LF), mask from
-//     HF+UHF (blur 2.7, fuzzy erosion), CombineChannelsToDiffmap
-//   then diffmap = 0.85 * full + 0.5 * upsampled(half) ; score = max ; p-norm = mean of 3-, 6-, 12-norms.
+//     sRGB u8 -> linear (the half-resolution level: 2x2 average, formed in the same kernel) -> blur sigma 1.2 (5-tap,
+//     mirrored) -> OpsinDynamicsImage -> XYB                                                          [k_ba_front]
+//     -> LF = blur 7.156 ; MF = blur 3.225 of (XYB - LF) ; HF = blur 1.564 of the rest ; UHF = rest, with the range
+//        shaping of SeparateFrequencies -> 10 planes; the mask input (DiffPrecompute of HF + UHF) falls out of the HF
+//        stage and is blurred with sigma 2.7                                           [k_ba_blur_h<33>, k_ba_blur_v_split]
+//   per reference and level: the mask values (fuzzy erosion + the two mask curves)                  [k_ba_mask_vals]
+//   per pair and level, ONE kernel:                                                                [k_ba_malta_l2_xy]
+//     Malta line filters (UHF, HF, MF; X and Y), asymmetric L2 (HF), L2 (MF), L2 (LF), CombineChannelsToDiffmap; the
+//     full-resolution level then forms diffmap = 0.85 * full + 0.5 * upsampled(half) in registers and reduces it
+//   score = max ; p-norm = mean of 3-, 6-, 12-norms.                                                    [k_ba_score]
 //
-// Long blurs (33 / 15 / 13 / 7 taps, borders re-normalised) are LDS-tiled with a register window
-// (k_ba_blur_h / k_ba_blur_v).  Build with -ffp-contract=off.
+// The 33-tap blur is a row kernel + a column kernel; the 15-, 13- and 7-tap blurs run row and column pass in one kernel
+// (LDS-tiled, borders re-normalised).  Build with -ffp-contract=off.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
