@@ -576,7 +576,9 @@ def main():
                 "batches_in_flight": depth,
                 "schedule": "serial (one stream, one kernel at a time)" if args.serial else
                             ("shape buckets and in-flight steps overlap on their own HIP streams; a batch's metric chains run "
-                             + ("side by side (CE_METRIC_STREAMS=fork)" if os.environ.get("CE_METRIC_STREAMS") == "fork" else "back to back")),
+                             + ("as CE_METRIC_STREAMS=%s says" % os.environ["CE_METRIC_STREAMS"] if os.environ.get("CE_METRIC_STREAMS") else
+                                "back to back (side by side only for a batch of <= 4 MP of pairs or one launched while nothing else is "
+                                "in flight on the device)")),
                 "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             },
             "roofline": roofline,
