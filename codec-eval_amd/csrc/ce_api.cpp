@@ -3,6 +3,7 @@
 // kinds, profiling hooks.  All device work is in the .hip files; there is no CPU compute
 // path here — if HIP is unavailable every entry point fails with CE_ERR_BACKEND.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <thread>
 #include <cmath>
@@ -744,16 +745,23 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         joined |= 1u << k;  // the context's stream waits for it after every chain has been launched
         return CE_OK;
     };
-    if (run_ssim2) {
-        int rc = chain(0, [&] { return ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs); });
-        if (rc != CE_OK) return rc;
-    }
-    if (run_dssim) {
-        int rc = chain(1, [&] { return ce_launch_dssim(b, d_refs, n_refs_used, n_pairs); });
-        if (rc != CE_OK) return rc;
-    }
-    if (run_ba) {
-        int rc = chain(2, [&] { return ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target); });
+    // launch order of the chains (0 SSIMULACRA2, 1 DSSIM, 2 Butteraugli); CE_FORK_ORDER=<permutation> for A/B runs of
+    // the forked schedule (profiles/r02_experiments.md section 19)
+    static const std::array<int, 3> fork_order = [] {
+        std::array<int, 3> o{0, 1, 2};
+        const char *e = std::getenv("CE_FORK_ORDER");
+        if (e && std::strlen(e) == 3) {
+            std::array<int, 3> t{e[0] - '0', e[1] - '0', e[2] - '0'};
+            if ((1 << t[0] | 1 << t[1] | 1 << t[2]) == 7 && t[0] >= 0 && t[1] >= 0 && t[2] >= 0) o = t;
+        }
+        return o;
+    }();
+    for (int i = 0; i < 3; i++) {
+        const int k = fork_mask == 7u ? fork_order[i] : i;
+        int rc = CE_OK;
+        if (k == 0 && run_ssim2) rc = chain(0, [&] { return ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs); });
+        if (k == 1 && run_dssim) rc = chain(1, [&] { return ce_launch_dssim(b, d_refs, n_refs_used, n_pairs); });
+        if (k == 2 && run_ba) rc = chain(2, [&] { return ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target); });
         if (rc != CE_OK) return rc;
     }
     for (int k = 0; k < 3; k++)
