@@ -152,6 +152,8 @@ void ce_free_xcd_list(ce_xcd_list *L)
     *L = ce_xcd_list{};
 }
 
+thread_local hipStream_t ce_tls_stream = nullptr;  // ce_internal.h: CE_STREAM
+
 extern "C" {
 
 const char *ce_version(void) { return "codec-eval_amd 0.2.0 (gfx950)"; }
@@ -730,21 +732,20 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         CE_HIP(ctx, hipEventRecord(b->ev_fork, base));
     }
     unsigned joined = 0;
-    auto chain = [&](int k, auto &&launch) -> int {
-        if (!(fork_mask & (1u << k))) return launch();
+    auto prepare_fork = [&](int k) -> int {  // the chain's stream exists and waits for the fork point
         if (!b->metric_stream[k]) {
             CE_HIP(ctx, hipStreamCreateWithFlags(&b->metric_stream[k], hipStreamNonBlocking));
             CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming));
         }
         CE_HIP(ctx, hipStreamWaitEvent(b->metric_stream[k], b->ev_fork, 0));
-        ctx->stream = b->metric_stream[k];  // the chain's launches go to "the context's stream"
-        const int rc = launch();
-        ctx->stream = base;
-        if (rc != CE_OK) return rc;
-        CE_HIP(ctx, hipEventRecord(b->ev_join[k], b->metric_stream[k]));
-        joined |= 1u << k;  // the context's stream waits for it after every chain has been launched
         return CE_OK;
     };
+    auto launch_metric = [&](int k) -> int {
+        return k == 0   ? ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs)
+               : k == 1 ? ce_launch_dssim(b, d_refs, n_refs_used, n_pairs)
+                        : ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target);
+    };
+    const bool runs[3] = {run_ssim2, run_dssim, run_ba};
     // launch order of the chains (0 SSIMULACRA2, 1 DSSIM, 2 Butteraugli); CE_FORK_ORDER=<permutation> for A/B runs of
     // the forked schedule (profiles/r02_experiments.md section 19)
     static const std::array<int, 3> fork_order = [] {
@@ -756,13 +757,65 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         }
         return o;
     }();
-    for (int i = 0; i < 3; i++) {
-        const int k = fork_mask == 7u ? fork_order[i] : i;
-        int rc = CE_OK;
-        if (k == 0 && run_ssim2) rc = chain(0, [&] { return ce_launch_ssim2(b, d_refs, n_refs_used, n_pairs); });
-        if (k == 1 && run_dssim) rc = chain(1, [&] { return ce_launch_dssim(b, d_refs, n_refs_used, n_pairs); });
-        if (k == 2 && run_ba) rc = chain(2, [&] { return ce_launch_butteraugli(b, d_refs, n_refs_used, n_pairs, intensity_target); });
-        if (rc != CE_OK) return rc;
+    // A forked SMALL batch is bound by the host: the ~50 launches of the three chains take ~0.2 ms to enqueue one after
+    // the other, and a chain cannot start before its first launch is enqueued.  So the chains of a fully forked batch are
+    // enqueued by one host thread each (the caller's + two helpers; CE_STREAM makes a launch function enqueue on its
+    // thread's chain stream); CE_FORK_THREADS=0 keeps the single-threaded enqueue for A/B runs.  Per-kernel event timing
+    // (ce_prof_*) keeps its bookkeeping on one thread.
+    static const bool fork_threads = [] { const char *e = std::getenv("CE_FORK_THREADS"); return !(e && e[0] == '0'); }();
+    if (fork_mask == 7u && fork_threads && !ctx->prof) {
+        int rcs[3] = {CE_OK, CE_OK, CE_OK};
+        std::string errs[3];
+        int last = -1;
+        for (int i = 0; i < 3; i++)
+            if (runs[fork_order[i]]) {
+                int rc = prepare_fork(fork_order[i]);
+                if (rc != CE_OK) return rc;
+                last = fork_order[i];
+            }
+        auto body = [&](int k) {
+            ce_tls_stream = b->metric_stream[k];
+            rcs[k] = launch_metric(k);
+            ce_tls_stream = nullptr;
+            if (rcs[k] == CE_OK && hipEventRecord(b->ev_join[k], b->metric_stream[k]) != hipSuccess) rcs[k] = CE_ERR_BACKEND;
+        };
+        std::vector<std::thread> helpers;
+        for (int i = 0; i < 3; i++) {
+            const int k = fork_order[i];
+            if (!runs[k] || k == last) continue;
+            helpers.emplace_back([&, k] {
+                if (hipSetDevice(ctx->device) != hipSuccess) {
+                    rcs[k] = CE_ERR_BACKEND;
+                    return;
+                }
+                body(k);
+            });
+        }
+        body(last);  // the caller's thread takes the chain that is enqueued last in the single-threaded order
+        for (auto &t : helpers) t.join();
+        for (int k = 0; k < 3; k++) {
+            if (!runs[k]) continue;
+            if (rcs[k] != CE_OK) return rcs[k];
+            joined |= 1u << k;
+        }
+    } else {
+        for (int i = 0; i < 3; i++) {
+            const int k = fork_mask == 7u ? fork_order[i] : i;
+            if (!runs[k]) continue;
+            if (!(fork_mask & (1u << k))) {
+                int rc = launch_metric(k);
+                if (rc != CE_OK) return rc;
+                continue;
+            }
+            int rc = prepare_fork(k);
+            if (rc != CE_OK) return rc;
+            ce_tls_stream = b->metric_stream[k];  // the chain's launches go to its own stream
+            rc = launch_metric(k);
+            ce_tls_stream = nullptr;
+            if (rc != CE_OK) return rc;
+            CE_HIP(ctx, hipEventRecord(b->ev_join[k], b->metric_stream[k]));
+            joined |= 1u << k;  // the context's stream waits for it after every chain has been launched
+        }
     }
     for (int k = 0; k < 3; k++)
         if (joined & (1u << k)) CE_HIP(ctx, hipStreamWaitEvent(base, b->ev_join[k], 0));

@@ -201,6 +201,11 @@ struct ce_batch {
 int ce_prof_begin(ce_ctx *ctx, const char *name, hipStream_t stream);
 void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream);
 
+// The stream a metric's launch function enqueues on: the context's stream, unless the calling thread is one of the helper
+// threads that enqueue a forked batch's chains side by side (ce_api.cpp: ce_batch_launch) - those set the override.
+extern thread_local hipStream_t ce_tls_stream;
+#define CE_STREAM(ctx_) (ce_tls_stream ? ce_tls_stream : (ctx_)->stream)
+
 #define CE_LAUNCH_ON(ctx_, stream_, name_, kern_, grid_, block_, shmem_, ...)                      \
     do {                                                                                           \
         int tok__ = (ctx_)->prof ? ce_prof_begin((ctx_), name_, (stream_)) : -1;                   \
@@ -208,7 +213,7 @@ void ce_prof_end(ce_ctx *ctx, int token, hipStream_t stream);
         if (tok__ >= 0) ce_prof_end((ctx_), tok__, (stream_));                                     \
     } while (0)
 #define CE_LAUNCH(ctx_, name_, kern_, grid_, block_, shmem_, ...)                                  \
-    CE_LAUNCH_ON(ctx_, (ctx_)->stream, name_, kern_, grid_, block_, shmem_, __VA_ARGS__)
+    CE_LAUNCH_ON(ctx_, CE_STREAM(ctx_), name_, kern_, grid_, block_, shmem_, __VA_ARGS__)
 
 #if defined(__HIPCC__)
 // Correctly rounded f32 quotients without the range-scaling steps of the compiler's expansion.  hipcc turns a / b into

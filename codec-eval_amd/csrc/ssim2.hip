@@ -916,8 +916,8 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     // default) and a stream that shares a hardware queue with a busy one waits for it - with three streams per batch
     // the second shape bucket's front end sat behind the first bucket's kernels for most of a step.
     // In the serial profiling mode everything stays on one stream so that per-kernel times do not overlap.
-    hipStream_t s0 = ctx->prof_serial ? ctx->stream : b->lvl_stream[0];
-    hipStream_t s1 = ctx->stream;
+    hipStream_t s0 = ctx->prof_serial ? CE_STREAM(ctx) : b->lvl_stream[0];
+    hipStream_t s1 = CE_STREAM(ctx);
     lvl_table tab{};
     lvl_table tab_v{};
     for (int s = 0; s < levels; s++) {
@@ -937,13 +937,13 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         g.npix[s] = d.w * d.h;
         g.nblk[s] = vblk;
         if (s == 0) {
-            if (s0 != ctx->stream) {
-                CE_HIP(ctx, hipEventRecord(b->ev_prep[0], ctx->stream));
+            if (s0 != CE_STREAM(ctx)) {
+                CE_HIP(ctx, hipEventRecord(b->ev_prep[0], CE_STREAM(ctx)));
                 CE_HIP(ctx, hipStreamWaitEvent(s0, b->ev_prep[0], 0));
             }
             rc = build_work_lists(b, n_pairs, hblk, vblk);
             if (rc != CE_OK) return rc;
-            if (ssim2_l0_chunk() && b->work_chunks_h.size() > 1 && s0 != ctx->stream && b->ev_done[2]) {
+            if (ssim2_l0_chunk() && b->work_chunks_h.size() > 1 && s0 != CE_STREAM(ctx) && b->ev_done[2]) {
                 // experiment: segment by segment on two alternating streams (row pass, then column pass of the same segment)
                 if (!b->lvl_stream[1]) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[1], hipStreamNonBlocking));
                 CE_HIP(ctx, hipStreamWaitEvent(b->lvl_stream[1], b->ev_prep[0], 0));
@@ -967,7 +967,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                          b->d_pair_ref, b->d_partials, d.w, d.h, d.pitch, d.plane, b->max_refs, 0u, b->max_vblocks, rg, tab,
                          (const uint2 *)b->d_work_v, (const uint32_t *)b->d_pair_first);
             }
-            if (s0 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[0], s0));
+            if (s0 != CE_STREAM(ctx)) CE_HIP(ctx, hipEventRecord(b->ev_done[0], s0));
         } else {
             const uint32_t l = tab.n++;
             tab_v.n = tab.n;
@@ -983,8 +983,8 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         }
     }
     if (tab.n) {
-        if (s1 != ctx->stream) {
-            CE_HIP(ctx, hipEventRecord(b->ev_prep[1], ctx->stream));
+        if (s1 != CE_STREAM(ctx)) {
+            CE_HIP(ctx, hipEventRecord(b->ev_prep[1], CE_STREAM(ctx)));
             CE_HIP(ctx, hipStreamWaitEvent(s1, b->ev_prep[1], 0));
         }
         rc = build_tail_lists(b, n_pairs, tab.blk_end[tab.n - 1], tab_v.blk_end[tab_v.n - 1]);
@@ -995,11 +995,11 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         CE_LAUNCH_ON(ctx, s1, "ssim2_vblur_ssim_L1-5", v_tail, dim3(b->work_len_vt), dim3(64), 0,
                      (const float *)nullptr, (const float *)nullptr, b->d_pair_ref, b->d_partials, 0u, 0u, 0u, (size_t)0, b->max_refs,
                      0u, b->max_vblocks, rg, tab_v, (const uint2 *)b->d_work_vt, (const uint32_t *)b->d_pair_first);
-        if (s1 != ctx->stream) CE_HIP(ctx, hipEventRecord(b->ev_done[1], s1));
+        if (s1 != CE_STREAM(ctx)) CE_HIP(ctx, hipEventRecord(b->ev_done[1], s1));
     }
-    if (s0 != ctx->stream) {
-        CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[0], 0));
-        if (tab.n && s1 != ctx->stream) CE_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_done[1], 0));
+    if (s0 != CE_STREAM(ctx)) {
+        CE_HIP(ctx, hipStreamWaitEvent(CE_STREAM(ctx), b->ev_done[0], 0));
+        if (tab.n && s1 != CE_STREAM(ctx)) CE_HIP(ctx, hipStreamWaitEvent(CE_STREAM(ctx), b->ev_done[1], 0));
     }
     if (b->keep_ref_pyramid && !cached) {
         b->ssim2_ref_src = d_refs;

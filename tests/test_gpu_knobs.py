@@ -40,6 +40,7 @@ SETTINGS = [
     {"CE_METRIC_STREAMS": "serial"},
     {"CE_METRIC_STREAMS": "fork:dssim,ba"},
     {"CE_METRIC_STREAMS": "fork", "CE_FORK_ORDER": "210"},
+    {"CE_METRIC_STREAMS": "fork", "CE_FORK_THREADS": "0"},
     {"CE_XCD_ORDER": "0"},
     {"CE_HV_ROWS": "64"},
     {"CE_MALTA_ROWS": "64"},
