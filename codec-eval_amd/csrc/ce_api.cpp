@@ -783,13 +783,17 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         for (int i = 0; i < 3; i++) {
             const int k = fork_order[i];
             if (!runs[k] || k == last) continue;
-            helpers.emplace_back([&, k] {
-                if (hipSetDevice(ctx->device) != hipSuccess) {
-                    rcs[k] = CE_ERR_BACKEND;
-                    return;
-                }
+            try {
+                helpers.emplace_back([&, k] {
+                    if (hipSetDevice(ctx->device) != hipSuccess) {
+                        rcs[k] = CE_ERR_BACKEND;
+                        return;
+                    }
+                    body(k);
+                });
+            } catch (...) {  // no thread to be had: enqueue this chain here (nothing may be thrown across the C ABI)
                 body(k);
-            });
+            }
         }
         body(last);  // the caller's thread takes the chain that is enqueued last in the single-threaded order
         for (auto &t : helpers) t.join();
