@@ -469,7 +469,13 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < n_threads; t++) pool.emplace_back(worker, t);
+    for (int t = 1; t < n_threads; t++) {
+        try {
+            pool.emplace_back(worker, t);
+        } catch (...) {  // no thread to be had: the calling thread's loop below takes whatever is left (nothing may be thrown across the C ABI)
+            break;
+        }
+    }
     worker(0);
     for (auto &th : pool) th.join();
     b->uploads_pending = true;
