@@ -30,7 +30,8 @@ def test_butteraugli_reference_cases(gpu_ctx, oracle, ce):
         gpu_ctx.calculate_butteraugli(small[: 7 * 9 * 3], small[: 7 * 9 * 3], 7, 9)
 
 
-SHAPES = [(8, 8), (9, 15), (15, 16), (16, 16), (33, 17), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512)]
+SHAPES = [(8, 8), (9, 15), (15, 16), (16, 16), (33, 17), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512),
+          (64, 33), (65, 32), (129, 65), (8, 200), (200, 8)]  # around the 64 x 32 / 64 x 64 tile edges of the fused blur and Malta kernels
 
 
 @pytest.mark.parametrize("w,h", SHAPES)

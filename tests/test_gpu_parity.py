@@ -393,7 +393,8 @@ def test_dssim_reference_cases(gpu_ctx, oracle, ce):
         gpu_ctx.calculate_dssim(np.zeros(50 * 50 * 3, np.uint8), grey, 100, 100)
 
 
-DSSIM_SHAPES = [(1, 1), (3, 2), (7, 9), (8, 8), (15, 17), (20, 20), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512), (512, 768)]
+DSSIM_SHAPES = [(1, 1), (3, 2), (7, 9), (8, 8), (15, 17), (20, 20), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512), (512, 768),
+                (33, 33), (65, 31), (32, 96)]  # one pixel over / under the 32 x 32 tile
 
 
 @pytest.mark.parametrize("w,h", DSSIM_SHAPES)
