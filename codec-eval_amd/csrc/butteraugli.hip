@@ -1256,17 +1256,22 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
             // LF: row pass sC -> sA, column pass + split: LF -> psy, raw MF -> sB
             CE_LAUNCH(ctx, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1, z0);
-            CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy,
-                      g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
-            // MF: row + column pass of raw MF (sB) + split: MF -> psy, raw HF -> sA (its old contents are dead)
-            // rows per block of the fused stages: 32 (default; 26 / 21 KB of LDS and ~100 / 56 registers: five blocks per CU)
+            // rows per block of the column / fused stages: 32 (default; 26 / 21 KB of LDS and ~100 / 56 registers: five blocks per CU)
             // or 64 (CE_HV_ROWS=64: smaller halo, 45 / 38 KB, three or four blocks).  Measured (profiles/r02_experiments.md
-            // section 18): 32 rows 0.50 + 0.33 ms per step solo against 0.53 + 0.41; headline equal, 4K grid +3 %
+            // section 18): 32 rows 0.50 + 0.33 ms per step solo against 0.53 + 0.41 (MF, HF), 0.48 against 0.53 (LF); headline
+            // equal, 4K grid +3 %
             static const int hv_rows = [] {
                 const char *e = std::getenv("CE_HV_ROWS");
                 return e && std::atoi(e) == 64 ? 64 : 32;
             }();
             const dim3 gvs32((g.w + 63) / 64, (g.h + 31) / 32, nz);
+            if (hv_rows == 32)
+                CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
+                          (const float *)sC, psy, g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
+            else
+            CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy,
+                      g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
+            // MF: row + column pass of raw MF (sB) + split: MF -> psy, raw HF -> sA (its old contents are dead)
             if (hv_rows == 32)
                 CE_LAUNCH(ctx, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sB,
                           (const float *)nullptr, psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr, sA);
