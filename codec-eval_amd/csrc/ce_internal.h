@@ -83,6 +83,13 @@ struct ce_xcd_list {
     uint32_t len = 0, cap = 0, version = ~0u, pairs = 0, tiles = 0;
 };
 
+// launch order of the streaming per-pair kernels (dssim.hip): one entry per BLOCK = a strip tile and the (up to four)
+// distorted images of one reference that its waves walk side by side
+struct ce_group_list {
+    void *d = nullptr;
+    uint32_t len = 0, cap = 0, version = ~0u, pairs = 0, strips = 0, rows = 0, h = 0;
+};
+
 struct ce_batch {
     ce_ctx *ctx = nullptr;
     uint32_t w = 0, h = 0, max_refs = 0, max_pairs = 0;
@@ -162,7 +169,8 @@ struct ce_batch {
     double *ds_part = nullptr; // [pairs][levels][2][blocks] partial sums (sum, abs-dev)
     double *ds_level_scores = nullptr;  // [pairs][levels]
     uint32_t ds_blocks = 0;
-    ce_xcd_list ds_work[CE_DSSIM_SCALES];  // k_dssim_compare's launch order, per level
+    ce_xcd_list ds_work[CE_DSSIM_SCALES];  // k_dssim_compare's launch order, per level (CE_DSSIM_COMPARE=tile: round 2's LDS-tile kernel)
+    ce_group_list ds_gwork[CE_DSSIM_SCALES];  // k_dssim_compare_stream's launch order, per level
     bool dssim_ready = false;
 
     // Butteraugli working set (butteraugli.hip): level 0 = full resolution, 1 = 2x-subsampled

@@ -15,8 +15,10 @@
 // oracle's f32 operation order (oracle/dssim.c), so planes are bit-identical; sums are f64.
 // Build with -ffp-contract=off.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ce_internal.h"
+#include "dssim_common.h"
 
 namespace {
 
@@ -94,10 +96,6 @@ __device__ __forceinline__ float pass3x3(const float *__restrict__ A, int lx, in
            at(ly, lx) * K4;
 }
 
-struct lvl_geom {
-    uint32_t w, h, pitch;
-    size_t plane;
-};
 
 // ---- Dssim::create_image for one level, fused: 32x32 tile + halo 4 in LDS ------------------------------------
 // linear RGB (level 0: sRGB u8 through the host-powf table) -> L*a*b* -> chroma pre-blur (2 passes) ->
@@ -545,6 +543,8 @@ void ce_dssim_free(ce_batch *b)
         hipFree(b->ds_rimg[l]); hipFree(b->ds_rmu[l]); hipFree(b->ds_rsq[l]);
         b->ds_rimg[l] = b->ds_rmu[l] = b->ds_rsq[l] = nullptr;
         ce_free_xcd_list(&b->ds_work[l]);
+        hipFree(b->ds_gwork[l].d);
+        b->ds_gwork[l] = ce_group_list{};
     }
     b->ds_ref_src = nullptr;
     hipFree(b->ds_part); hipFree(b->ds_level_scores);
@@ -587,7 +587,8 @@ static int dssim_allocate(ce_batch *b)
         CE_HIP(ctx, hipMalloc(&b->ds_rsq[l], rb));
     }
     CE_HIP(ctx, hipMalloc(&b->ds_map, (size_t)b->max_pairs * p0 * sizeof(float)));
-    b->ds_blocks = ((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4);
+    // partial sums per (pair, level): the absdev kernel's blocks, or the compare kernel's strip tiles (>= 8 rows each)
+    b->ds_blocks = std::max(((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4), ((b->ds[0].w + CE_DSSIM_STRIP - 1) / CE_DSSIM_STRIP) * ((b->ds[0].h + 7) / 8));
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->ds_level_scores, (size_t)b->max_pairs * CE_DSSIM_SCALES * sizeof(double)));  // avg, then score
     return CE_OK;
@@ -618,6 +619,10 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     const bool cached = b->keep_ref_pyramid && b->ds_ref_src == d_refs && b->ds_ref_count >= n_refs_used;
     const uint32_t z0 = cached ? n_refs_used : 0;
     if (!cached) b->ref_builds[1]++;
+    static const bool tile_compare = [] {  // CE_DSSIM_COMPARE=tile: round 2's LDS-tile compare kernel (A/B knob)
+        const char *e = std::getenv("CE_DSSIM_COMPARE");
+        return e && std::string(e) == "tile";
+    }();
     ds_geom g{};
     for (int l = 0; l < b->ds_levels; l++) {
         const auto &d = b->ds[l];
@@ -635,12 +640,18 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
                       ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img,
                       b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
         // compare per pair
-        if ((rc = ce_build_xcd_list(b, n_pairs, tiles.x * tiles.y, &b->ds_work[l])) != CE_OK) return rc;
-        CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, (const float *)b->ds_img,
-                  (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
-                  b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
+        uint32_t n_part = 0;
+        if (tile_compare) {
+            if ((rc = ce_build_xcd_list(b, n_pairs, tiles.x * tiles.y, &b->ds_work[l])) != CE_OK) return rc;
+            CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, (const float *)b->ds_img,
+                      (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
+                      b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
+            n_part = tiles.x * tiles.y;
+        } else {
+            if ((rc = ce_dssim_compare_stream(b, l, n_pairs, &n_part)) != CE_OK) return rc;
+        }
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
-                  (uint32_t)b->ds_levels, b->ds_blocks, tiles.x * tiles.y);
+                  (uint32_t)b->ds_levels, b->ds_blocks, n_part);
         const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);
         CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, b->ds_map, b->ds_level_scores, b->ds_part, d.w, d.h,
                   d.pitch, d.plane, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);

@@ -1,0 +1,271 @@
+// DSSIM on gfx950, the streaming kernels (see dssim.hip for the metric's structure and the reference lines it replaces:
+// /root/reference/src/metrics/dssim.rs:40-71 -> dssim_core::Dssim::compare).
+// This file is compiled with -fno-slp-vectorize: packed f32 instructions do not pay on gfx950 (profiles/r02_experiments.md
+// section 4) and pairing registers for them costs moves in a kernel that is nothing but register-to-register arithmetic.
+// Build with -ffp-contract=off.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "ce_internal.h"
+#include "dssim_common.h"
+
+namespace {
+
+// ---- Dssim::compare for one level as a STREAM: no LDS, no barrier --------------------------------------------------
+// One wave owns a 64-column strip (60 output columns + halo 2 on either side) of one pair and walks down its rows.
+// Every value a 3x3 pass needs from the neighbouring columns comes from the neighbouring LANES (DPP wave shifts, a
+// full-rate VALU move), every value it needs from the neighbouring rows from four registers per plane (rows9 below):
+// the partial sums of the oracle's order "corners, edges, centre".  Nine planes (img2, img1 * img2, img2^2 of three
+// channels) x two passes = 72 window registers; the pass-1 output of a row feeds pass 2 in the same step, so nothing is
+// ever staged.  Same taps, same order, same edge replication as dssim.hip's pass3x3: bit-identical planes.
+// The waves of a block take CONSECUTIVE entries of a work list in which the distorted images of one reference follow each
+// other on the same strip: they request the same reference lines at the same time, so the reference's nine planes come
+// from HBM once per reference, not once per pair.
+constexpr int CS_OUT = CE_DSSIM_STRIP;  // output columns of a strip
+constexpr int CS_WAVES = 4;
+
+__device__ __forceinline__ float lane_left(float v)  // the value of lane - 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right(float v)  // the value of lane + 1
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ld_at(const float *base, uint32_t byte_off)  // uniform base + 32-bit lane offset: saddr form
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// One row of the nine planes as a 3x3 pass keeps it.  Everything a row contributes through its neighbouring columns is
+// formed when the row ARRIVES (two lane shifts per value): lr = l + r, the corner pair it will contribute as the row above, and e = (c_above + l) + r, the first
+// three of the four "edges" terms of the output it will be the middle row of.  The middle row keeps (c, e, lr), the row
+// above only lr.  Three such rows rotate BY NAME through the unrolled loop body (no register moves).
+struct rows9 {
+    float c[9], e[9], lr[9];
+};
+struct rowin {
+    float a[3], r[3];  // the distorted / the reference image's row, one row ahead of pass 1
+};
+
+// the row below (N, value v) has arrived; returns the pass's output for the middle row M (oracle order: corners, edges,
+// centre).  c_above = the value above v as the pass's input has it (M.c, or v itself where v is the image's first row).
+__device__ __forceinline__ float pass_rows(const rows9 &P, const rows9 &M, rows9 &N, int k, float v, float c_above)
+{
+    const float K0 = 0.095332f, K1 = 0.118095f, K4 = 0.146293f;
+    const float corners = (P.lr[k] + lane_left(v)) + lane_right(v);  // ((tl + tr) + bl) + br
+    const float edges = M.e[k] + v;                                  // ((t + l) + r) + b
+    N.c[k] = v;
+    N.e[k] = (c_above + lane_left(v)) + lane_right(v);
+    N.lr[k] = lane_left(v) + lane_right(v);
+    return corners * K0 + edges * K1 + M.c[k] * K4;
+}
+
+struct cmp_planes {  // wave-uniform plane bases (scalar registers); a lane adds a 32-bit byte offset
+    const float *t[3], *r[3], *u[3], *q[3];
+};
+
+template <bool EDGE>
+__device__ __forceinline__ double dssim_compare_strip(const cmp_planes &pl, float *__restrict__ map, const lvl_geom &g, int xs, int y0, int y1)
+{
+    const int w = (int)g.w, h = (int)g.h, lane = (int)(threadIdx.x & 63);
+    const uint32_t pitch = g.pitch;
+    const int X = xs + lane - 2;
+    const uint32_t Xc = (uint32_t)min(max(X, 0), w - 1);  // clamped loads: pass 1 sees the replicated edge columns for free
+    const bool out_lane = lane >= 2 && lane < 2 + CS_OUT && X < w;
+    // pass 2 replicates ITS input's edge columns: the lane left of column 0 / right of column w - 1 takes its neighbour's value
+    const bool before_first = X == -1, after_last = X == w;
+    auto row_off = [&](int y) { return ((uint32_t)min(max(y, 0), h - 1) * pitch + Xc) * 4u; };
+    double val = 0.0;
+    // step i: input row i arrives (cur; nxt is requested for step i + 1), pass 1 puts out row t = i - 1, pass 2 row y = i - 2
+    // ENDS: the step may be the one that meets the first / last row of the image (first and last loop body only)
+    auto step = [&](auto ends, const rows9 &P1, rows9 &M1, rows9 &N1, const rows9 &P2, rows9 &M2, rows9 &N2, const rowin &cur, rowin &nxt, int i)
+                    __attribute__((always_inline)) {
+        constexpr bool ENDS = decltype(ends)::value;
+        const int t = i - 1, y = i - 2;
+        float u1[3], q1[3];  // the reference's mu / blur(img^2) of the row pass 2 puts out at the end of this step
+        {
+            const uint32_t o = row_off(i + 1), os = row_off(y);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                nxt.a[c] = ld_at(pl.t[c], o);
+                nxt.r[c] = ld_at(pl.r[c], o);
+                u1[c] = ld_at(pl.u[c], os);
+                q1[c] = ld_at(pl.q[c], os);
+            }
+        }
+        // channel by channel (the scheduling barrier keeps the compiler from starting all nine planes at once)
+        float O[9];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float v3[3] = {cur.a[c], cur.r[c] * cur.a[c], cur.a[c] * cur.a[c]};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int k = 3 * c + j;
+                float T = pass_rows(P1, M1, N1, k, v3[j], M1.c[k]);
+                if (EDGE) {
+                    const float fl = lane_right(T), fr = lane_left(T);
+                    T = before_first ? fl : (after_last ? fr : T);
+                }
+                // the rows above / below the image replicate the first / last row of pass 2's INPUT (wave-uniform tests)
+                float c_above = M2.c[k];
+                if (ENDS && t == h) T = M2.c[k];
+                if (ENDS && t == 0) c_above = T;
+                O[k] = pass_rows(P2, M2, N2, k, T, c_above);
+                if (ENDS && t == 0) M2.lr[k] = N2.lr[k];  // row -1 = row 0: the next step's corner pair from above
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (y >= y0 && y < y1) {
+            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
+            float m11[3], m12[3], m22[3], s1[3], s2[3], s12c[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float u2v = O[3 * c + 0], s12 = O[3 * c + 1], q2 = O[3 * c + 2];
+                m11[c] = u1[c] * u1[c];
+                m12[c] = u1[c] * u2v;
+                m22[c] = u2v * u2v;
+                s1[c] = q1[c] - m11[c];
+                s2[c] = q2 - m22[c];
+                s12c[c] = s12 - m12[c];
+            }
+#define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
+            const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
+            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12c);
+#undef AVG3
+            const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
+            if (out_lane) {
+                map[(uint32_t)y * pitch + (uint32_t)X] = ssim;
+                val += (double)ssim;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    rows9 s0, s1, s2, z0, z1, z2;
+#pragma unroll
+    for (int k = 0; k < 9; k++) s0.lr[k] = s1.c[k] = s1.e[k] = s1.lr[k] = z0.lr[k] = z1.c[k] = z1.e[k] = z1.lr[k] = 0.f;
+    rowin L0, L1, L2;
+    // input rows y0 - 2 .. y1 + 1, three per loop body (up to two surplus steps at the end put nothing out).  The top
+    // block starts at row -1, so that the step that meets the image's first row (t = 0, i = 1) is in the first body; the
+    // one that meets its last row (t = h, i = y1 + 1) is in the last body by construction: the bodies between are plain.
+    const int i0 = y0 == 0 ? -1 : y0 - 2, n_bodies = (y1 + 1 - i0) / 3 + 1;
+    {
+        const uint32_t o = row_off(i0);
+#pragma unroll
+        for (int c = 0; c < 3; c++) L0.a[c] = ld_at(pl.t[c], o), L0.r[c] = ld_at(pl.r[c], o);
+    }
+    auto body = [&](auto ends, int i) __attribute__((always_inline)) {
+        step(ends, s0, s1, s2, z0, z1, z2, L0, L1, i);
+        step(ends, s1, s2, s0, z1, z2, z0, L1, L2, i + 1);
+        step(ends, s2, s0, s1, z2, z0, z1, L2, L0, i + 2);
+    };
+    int i = i0;
+    body(std::true_type{}, i);
+    i += 3;
+#pragma unroll 1
+    for (int b = 1; b < n_bodies - 1; b++, i += 3) body(std::false_type{}, i);
+    if (n_bodies > 1) body(std::true_type{}, i);
+    return val;
+}
+
+__global__ __launch_bounds__(CS_WAVES * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_dssim_compare_stream(const float *__restrict__ img, const float *__restrict__ rimg,
+                                                                        const float *__restrict__ rmu, const float *__restrict__ rsq,
+                                                                        const uint32_t *__restrict__ pair_ref, float *__restrict__ map,
+                                                                        double *__restrict__ part, lvl_geom g, uint32_t level,
+                                                                        uint32_t n_levels, uint32_t n_blocks,
+                                                                        const uint2 *__restrict__ work, uint32_t strips, uint32_t rows)
+{
+    // wave j of block b takes entry 4 * (b / 8) + j of XCD class b % 8 (the list interleaves the eight classes)
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint2 wi = work[((blockIdx.x >> 3) * CS_WAVES + wv) * 8 + (blockIdx.x & 7)];
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(wi.x), p = __builtin_amdgcn_readfirstlane(wi.y);
+    if (tile == ~0u) return;  // padding entry; no barrier anywhere below: a wave may leave alone
+    const uint32_t ref = __builtin_amdgcn_readfirstlane(pair_ref[p]);
+    const int xs = (int)(tile % strips) * CS_OUT, y0 = (int)((tile / strips) * rows), y1 = min(y0 + (int)rows, (int)g.h);
+    cmp_planes pl;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        pl.t[c] = img + ((size_t)p * 3 + c) * g.plane;
+        pl.r[c] = rimg + ((size_t)ref * 3 + c) * g.plane;
+        pl.u[c] = rmu + ((size_t)ref * 3 + c) * g.plane;
+        pl.q[c] = rsq + ((size_t)ref * 3 + c) * g.plane;
+    }
+    float *pmap = map + (size_t)p * g.plane;
+    double val = (xs == 0 || xs + CS_OUT + 2 >= (int)g.w) ? dssim_compare_strip<true>(pl, pmap, g, xs, y0, y1)
+                                                          : dssim_compare_strip<false>(pl, pmap, g, xs, y0, y1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) val += __shfl_down(val, off, 64);
+    if ((threadIdx.x & 63) == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + tile] = val;
+}
+
+// Launch order of k_dssim_compare_stream: entries (strip tile, pair); a block's CS_WAVES waves take consecutive entries of
+// one XCD class.  Workgroups reach the 8 XCDs round-robin by launch id; all entries of one (reference, row block) - its
+// strips, and on each strip the reference's distorted images one after the other - go to ONE class, so that the
+// 128-byte lines two neighbouring strips share (a strip starts two columns left of a multiple of 60) and the reference's
+// lines are fetched into one L2 (and mostly by one CU) while they are in use.
+int build_stream_list(ce_batch *b, uint32_t n_pairs, uint32_t strips, uint32_t rows, uint32_t h, ce_group_list *L)
+{
+    if (L->d && L->version == b->pair_ref_version && L->pairs == n_pairs && L->strips == strips && L->rows == rows && L->h == h)
+        return CE_OK;
+    ce_ctx *ctx = b->ctx;
+    std::vector<std::vector<uint32_t>> pairs_of(b->max_refs);
+    for (uint32_t p = 0; p < n_pairs; p++) pairs_of[b->h_pair_ref[p]].push_back(p);
+    const uint32_t row_blocks = (h + rows - 1) / rows;
+    std::vector<uint2> cls[8];
+    uint32_t k = 0;
+    for (uint32_t r = 0; r < b->max_refs; r++) {
+        if (pairs_of[r].empty()) continue;
+        for (uint32_t rb = 0; rb < row_blocks; rb++, k++)
+            for (uint32_t s = 0; s < strips; s++)
+                for (uint32_t p : pairs_of[r]) cls[k & 7].push_back(make_uint2(rb * strips + s, p));
+    }
+    size_t longest = 0;
+    for (auto &v : cls) longest = std::max(longest, v.size());
+    longest = (longest + CS_WAVES - 1) / CS_WAVES * CS_WAVES;
+    std::vector<uint2> flat(longest * 8, make_uint2(~0u, 0u));
+    for (uint32_t x = 0; x < 8; x++)
+        for (size_t sl = 0; sl < cls[x].size(); sl++) flat[sl * 8 + x] = cls[x][sl];
+    if (flat.size() > L->cap) {
+        if (L->d) CE_HIP(ctx, hipFree(L->d));
+        L->d = nullptr;
+        L->cap = 0;
+        CE_HIP(ctx, hipMalloc(&L->d, flat.size() * sizeof(uint2)));
+        L->cap = (uint32_t)flat.size();
+    }
+    CE_HIP(ctx, hipMemcpyAsync(L->d, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is pageable and goes out of scope
+    L->len = (uint32_t)flat.size();
+    L->version = b->pair_ref_version;
+    L->pairs = n_pairs;
+    L->strips = strips;
+    L->rows = rows;
+    L->h = h;
+    return CE_OK;
+}
+
+// rows a wave of the streaming kernels walks: as many as still leave every SIMD a few waves (a wave re-reads 4 rows of halo)
+uint32_t stream_rows(uint32_t strips, uint32_t h, uint32_t n_images)
+{
+    uint32_t rows = 64;
+    while (rows > 8 && (size_t)strips * ((h + rows - 1) / rows) * n_images < 8192) rows /= 2;
+    return rows;
+}
+
+}  // namespace
+
+int ce_dssim_compare_stream(ce_batch *b, int l, uint32_t n_pairs, uint32_t *n_part)
+{
+    ce_ctx *ctx = b->ctx;
+    const auto &d = b->ds[l];
+    const lvl_geom lg{d.w, d.h, d.pitch, d.plane};
+    const uint32_t strips = (d.w + CS_OUT - 1) / CS_OUT, rows = stream_rows(strips, d.h, n_pairs);
+    const int rc = build_stream_list(b, n_pairs, strips, rows, d.h, &b->ds_gwork[l]);
+    if (rc != CE_OK) return rc;
+    CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare_stream, dim3(b->ds_gwork[l].len / CS_WAVES), dim3(CS_WAVES * 64), 0,
+              (const float *)b->ds_img, (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l],
+              b->d_pair_ref, b->ds_map, b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks,
+              (const uint2 *)b->ds_gwork[l].d, strips, rows);
+    *n_part = strips * ((d.h + rows - 1) / rows);
+    return CE_OK;
+}
