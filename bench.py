@@ -2,370 +2,470 @@
 """bench.py — BASELINE.json's metric on the MI355X hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Default workload: the metric AS NAMED — "metric MP/s (SSIMULACRA2+DSSIM+Butteraugli)" — on BASELINE.json configs[1]'s
-grid: 24 synthetic references in Kodak's shapes (18 of 768x512, 6 of 512x768) x q in {75, 85, 95} = 72
-(reference, distorted) pairs per GPU, every pair scored by all three perceptual metrics in one launch
-(the call shape of crates/codec-compare/src/full_comparison.rs:149-177).  Inputs are uploaded once and are resident
-in HBM when the timed region starts.  A step = one pass of the hot path over the rank's whole grid, scores returned to
-the host.  value = reference pixels x (pair, metric) evaluations / wall time, plus a per-metric
-breakdown (each metric alone on the same grid).
+N > 1 runs either way: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the
+driver's form), or as the plain command above — then this process, which makes no GPU call, starts N rank processes
+itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and waits for them.
 
---config 2..5 select BASELINE.json's other configs (2 = configs[1] as written: SSIMULACRA2 only; 3 = 4K Butteraugli;
-4 = CID22 x 8 qualities, SSIMULACRA2 + DSSIM; 5 = codec-iter dense sweep, all metrics, XYB on/off).
+Default workload: the metric AS NAMED — "metric MP/s (SSIMULACRA2+DSSIM+Butteraugli)" — on north_star's own sweep,
+"the Kodak+CID22 sweep at 1 GPU": 24 synthetic references in Kodak's shapes (18 of 768x512, 6 of 512x768) x q in
+{75, 85, 95} (codec-iter "quick", crates/codec-iter/src/main.rs:197) PLUS 250 CID22-shaped 512x512 references x the
+standard 8 qualities (main.rs:198) = 2072 (reference, distorted) pairs, 552 MP per GPU, every pair scored by all three
+perceptual metrics (the call shape of crates/codec-compare/src/full_comparison.rs:149-177).  The grid is resident in
+HBM as six batches (two Kodak shape buckets, four CID22 chunks of <= 64 references) when the timed region starts; a
+step = one pass of the hot path over the rank's whole grid, scores returned to the host; a few batches are in flight
+at a time.  value = reference pixels x (pair, metric) evaluations / wall time.  `kodak_only` repeats
+round 1-2's headline (the 72-pair Kodak grid alone) for continuity.
+
+--config 2..5 select BASELINE.json's other configs (2 = configs[1] as written: Kodak grid, SSIMULACRA2 only; 3 = 4K
+Butteraugli; 4 = CID22 x 8 qualities, SSIMULACRA2 + DSSIM; 5 = codec-iter dense sweep, all metrics, XYB on/off).
 
 N > 1: ONE global grid is partitioned over the ranks by codec-eval_amd/sharding.py (by reference image; config 5
 falls back to (image, codec-config) units when that balances better), no data-path collective, the scores are
-gathered to rank 0 in global (image, variant, quality) order and a sample of them is recomputed there.  Default
-workload: the global grid is N Kodak-24 sets (24 N references), so per-GPU work is fixed => "scaling": "weak";
-configs 4 and 5 are FIXED grids => "scaling": "strong".  torch.distributed is control plane only (barriers,
-max-over-ranks of the time, the gather of the tiny score lists).
+gathered to rank 0 in global order and a sample of them is recomputed there.  Default workload: the global grid is N
+sweeps, so per-GPU work is fixed => "scaling": "weak"; the same line then carries `strong`: BASELINE configs[3]'s
+FIXED grid (250 x 8, SSIMULACRA2 + DSSIM) partitioned over the same ranks and timed after the default one.  configs 4
+and 5 as the main workload are fixed grids => "strong".  torch.distributed (gloo, host side only) carries the barriers,
+the max-over-ranks of the time and the gather of the tiny score lists — no RCCL anywhere (north_star).
 
-Extra JSON objects: "roofline" (the dominant kernel: algorithmic bytes per launch over its HIP-event duration, alone
-on the GPU = `frac`, and in the timed region = `in_region_*`; every kernel's row in `kernels`), "per_metric",
-"end_to_end" (page-locked host buffers in, scores out, uploads included) and "cpu_baseline" (the C oracle — a scalar
-restatement, not the Rust crates — on this host's cores; rank 0, N = 1 only).
+Extra JSON objects: "roofline" (the dominant kernel: algorithmic bytes per launch over its HIP-event duration alone on
+the GPU = `frac`, in the timed region = `in_region_*`; the roof that binds it from the SQ counters under profiles/;
+every kernel's row in `kernels`; the step against this round's and round 2's frozen byte model), "per_metric",
+"kodak_only", "per_call" (one blocking call per encode: crates/codec-iter/src/gpu.rs:83-109), "end_to_end"
+(page-locked host buffers in, scores out), "cpu_baseline" (the C oracle — a scalar restatement, not the Rust crates —
+on this host's cores, pool size swept; rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
+import collections
+import csv
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 # before anything initialises HIP (torch does): see codec-eval_amd/__init__.py
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC_NAMES = ("dssim", "ssimulacra2", "butteraugli", "psnr")
+KODAK_QUALITIES = (75, 85, 95)  # codec-iter "quick" preset, crates/codec-iter/src/main.rs:197
+CID_CHUNK_REFS = 64             # references per resident CID22 batch (x 8 qualities = 512 pairs, ~37 GB of working planes)
+SEED = {"kodak": 1000, "uhd": 2000, "cid": 3000, "dense": 4000}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 4, 5),
-                    help="0 (default): BASELINE configs[1]'s Kodak grid scored by SSIMULACRA2 + DSSIM + Butteraugli (the metric as "
-                         "named); 2..5: BASELINE.json configs[1..4] as written (1-based), scaled with --refs")
-    ap.add_argument("--refs", type=int, default=0, help="override the number of reference images (configs 3-5)")
-    ap.add_argument("--quick", action="store_true", help="6 references instead of 24 per Kodak set (smoke runs)")
+                    help="0 (default): the Kodak + CID22 sweep scored by SSIMULACRA2 + DSSIM + Butteraugli (the metric as named); "
+                         "2..5: BASELINE.json configs[1..4] as written (1-based), scaled with --refs")
+    ap.add_argument("--refs", type=int, default=0, help="override the number of reference images (configs 3-5; config 0: CID22 references)")
+    ap.add_argument("--quick", action="store_true", help="6 Kodak + 8 CID22 references (smoke runs)")
+    ap.add_argument("--kodak-only", action="store_true", help="config 0 without the CID22 part (round 1-2's headline grid as the main workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solo", action="store_true", help="skip the solo pass (no per-kernel table; roofline from in-region events only)")
     ap.add_argument("--no-events", action="store_true", help="no HIP events in the timed region")
     ap.add_argument("--no-per-metric", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-per-call", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1, config 0: skip the fixed-grid (strong scaling) leg")
     ap.add_argument("--all-events", action="store_true", help="events around every kernel in the timed region, not only the dominant one")
     ap.add_argument("--serial", action="store_true",
                     help="timed region with every launch on one stream, one kernel at a time (for rocprofv3 traces whose per-kernel "
                          "durations are the kernels' own, not their share of an overlapped schedule)")
     ap.add_argument("--one-shape", action="store_true",
-                    help="experiment: all 24 references of a Kodak set in the 768x512 shape (one bucket, same pixel count) - the upper "
-                         "bound of what a merged two-bucket launch could gain")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight per shape bucket (default 2: step k+1 is launched before step k's scores are collected)")
+                    help="experiment: all 24 references of a Kodak set in the 768x512 shape (one bucket, same pixel count)")
+    ap.add_argument("--depth", type=int, default=0, help="copies of a SMALL grid's batches (default 2 when the grid is under 1 GP per step, else 1)")
+    ap.add_argument("--inflight", type=int, default=0, help="batches launched and not yet collected (default: 2 * batches - 1 of a small grid, 3 of the sweep)")
     return ap.parse_args()
+
+
+# ---- plain `python bench.py --gpus N`: start the ranks ourselves ------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """The parent makes no GPU call (nothing below imports torch or the library): N fresh rank processes, gloo rendezvous
+    on 127.0.0.1, rank 0 prints the line on the stdout they all inherit."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0:
+                    rc = rc or r
+                    for q in procs:  # a rank failed: the others would wait at a barrier for ever
+                        q.terminate()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            q.terminate()
+        rc = 130
+    return rc
+
+
+def host_cpus() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+# ---- the global grid and a rank's shard of it (synthetic, every image seeded by its GLOBAL index) ---------------------------
+class Workload:
+    """launches = [(Grid, MetricConfig, group)]: one resident batch each.  key(group, pair_id) orders the gathered scores."""
+
+    def __init__(self, cfg_id, args, rank, world, ce, wl, sh, as_strong=False):
+        self.cfg_id, self.rank, self.world = cfg_id, rank, world
+        self.scaling, self.launches = "weak", []
+        quick = args.quick
+        if cfg_id in (0, 2):
+            n_k = 6 if quick else 24
+            n_c = 0 if (cfg_id == 2 or args.kodak_only) else (args.refs or (8 if quick else 250))
+            kshapes = wl.kodak_corpus_shapes(world) if not args.one_shape else [(768, 512)] * (24 * world)
+            kids = [g for g in range(24 * world) if not quick or g % 24 in (0, 1, 2, 3, 4, 18)]  # --quick: 5 landscape + 1 portrait per set
+            cids = list(range(n_c * world))
+            # one partition over every reference of the global grid: load = pixels x distorted images
+            pix = [kshapes[g][0] * kshapes[g][1] for g in kids] + [512 * 512] * len(cids)
+            tests = [len(KODAK_QUALITIES)] * len(kids) + [len(wl.STANDARD_QUALITIES)] * len(cids)
+            self.mode, units, _ = sh.plan_partition(pix, tests, 1, world)
+            mine = sorted({i for i, _ in units[rank]})
+            my_k = [kids[i] for i in mine if i < len(kids)]
+            my_c = [cids[i - len(kids)] for i in mine if i >= len(kids)]
+            cfg = ce.MetricConfig.perceptual() if cfg_id == 0 else ce.MetricConfig.ssimulacra2_only()
+            for j in range(0, len(my_c), CID_CHUNK_REFS):  # the big chunks first: the small Kodak buckets fill the tail of a step
+                self.launches.append((wl.cid22_like(len(cids), seed0=SEED["cid"], only=my_c[j:j + CID_CHUNK_REFS]), cfg, "cid"))
+            if my_k:
+                grids = (wl.kodak_corpus_shard(my_k, KODAK_QUALITIES, seed0=SEED["kodak"]) if not args.one_shape else
+                         [wl._grid("kodak-768x512", 768, 512, 0, SEED["kodak"], KODAK_QUALITIES, only=my_k)])
+                self.launches += [(g, cfg, "kodak") for g in grids]
+            self.cfg = cfg
+            self.n_global_refs = len(kids) + len(cids)
+            what = "SSIMULACRA2 + DSSIM + Butteraugli on every pair" if cfg_id == 0 else "SSIMULACRA2 only"
+            sets = f"{world} sets of " if world > 1 else ""
+            if n_c:
+                self.workload = (f"north_star's sweep: {sets}Kodak-24 x q75/85/95 (768x512 x18 + 512x768 x6 buffers) + CID22-shaped {n_c} x 512x512 x "
+                                 f"8 qualities (50..95) = {len(kids) * 3 // world + 8 * n_c} pairs per GPU, {what}")
+            else:
+                self.workload = f"BASELINE configs[1] grid: {sets}Kodak-24 x 3 quality levels (q75/85/95; 768x512 x18 + 512x768 x6 buffers) per GPU, {what}"
+            if world > 1:
+                self.workload += "; ONE global grid partitioned by reference"
+        elif cfg_id == 3:
+            n = args.refs or 16
+            pix = [3840 * 2160] * (n * world)
+            self.mode, units, _ = sh.plan_partition(pix, [1] * len(pix), 1, world)
+            mine = sorted({i for i, _ in units[rank]})
+            self.cfg = ce.MetricConfig(butteraugli=True)
+            self.launches = [(wl.uhd_pairs(n * world, seed0=SEED["uhd"], only=mine), self.cfg, "uhd")]
+            self.n_global_refs = n * world
+            self.workload = f"BASELINE configs[2]: {n} synthetic 3840x2160 pairs per GPU, Butteraugli (max-norm + 3-norm)"
+        elif cfg_id == 4:
+            n = args.refs or (8 * world if (quick and as_strong) else 250)
+            self.scaling = "strong"
+            self.mode, units, _ = sh.plan_partition([512 * 512] * n, [len(wl.STANDARD_QUALITIES)] * n, 1, world)
+            mine = sorted({i for i, _ in units[rank]})
+            self.cfg = ce.MetricConfig(ssimulacra2=True, dssim=True)
+            for j in range(0, len(mine), 2 * CID_CHUNK_REFS):
+                self.launches.append((wl.cid22_like(n, seed0=SEED["cid"], only=mine[j:j + 2 * CID_CHUNK_REFS]), self.cfg, "cid"))
+            self.n_global_refs = n
+            self.workload = f"BASELINE configs[3]: {n} CID22-shaped 512x512 refs x 8 qualities = {8 * n} pairs (fixed grid, partitioned by reference), SSIMULACRA2 + DSSIM"
+        else:
+            n = args.refs or 15
+            self.scaling = "strong"
+            # codec configs of crates/codec-iter/src/main.rs:474-499: {4:4:4, 4:2:0} x {XYB off, on}; variant v = 2 * xyb + s420
+            self.mode, units, _ = sh.plan_partition([512 * 512] * n, [4 * len(wl.DENSE_QUALITIES)] * n, 4, world)
+            for xyb in (0, 1):
+                u = sorted((i, v & 1) for i, v in units[rank] if (v >> 1) == xyb)
+                if u:
+                    c = ce.MetricConfig.all()
+                    self.launches.append((wl.codec_iter_dense(n, seed0=SEED["dense"], units=u), c.with_xyb_roundtrip() if xyb else c, "dense"))
+            self.cfg = ce.MetricConfig.all()
+            self.n_global_refs = n
+            self.workload = (f"BASELINE configs[4]: {n} 512x512 refs x 25 qualities x {{4:4:4, 4:2:0}} x {{XYB off, on}} = {100 * n} pairs "
+                             f"(fixed grid), PSNR + SSIMULACRA2 + DSSIM + Butteraugli, XYB roundtrip on the reference for the XYB-on half")
+        self.metrics_on = [m for m in METRIC_NAMES if getattr(self.cfg, m)]
+        # (pair, metric) evaluations per pair: the perceptual metrics BASELINE's metric names; PSNR rides along for free
+        # (6 B/px) and is NOT counted, except in a PSNR-only configuration
+        self.n_eval_metrics = len([m for m in self.metrics_on if m != "psnr"]) or 1
+        self.pairs_per_step = sum(len(g.pairs) for g, _, _ in self.launches)
+        self.mp_per_step = sum(g.megapixels for g, _, _ in self.launches)
+
+    def key(self, group, c, pid):
+        return (group, pid[0], pid[1] + (2 if c.xyb_roundtrip and self.cfg_id == 5 else 0), pid[2])
+
+    def regenerate(self, key, wl, world):
+        """(reference, distorted, w, h, config) of one cell of the GLOBAL grid, from its key alone."""
+        group, gi, v, qi = key
+        c = self.cfg
+        if group == "kodak":
+            w_, h_ = wl.kodak_corpus_shapes(world)[gi]
+            ref = wl.make_reference(w_, h_, SEED["kodak"] + gi)
+            return ref, wl.distort(ref, KODAK_QUALITIES[qi]), w_, h_, c
+        if group == "uhd":
+            ref = wl.make_reference(3840, 2160, SEED["uhd"] + gi)
+            return ref, wl.distort(ref, 85), 3840, 2160, c
+        if group == "cid":
+            ref = wl.make_reference(512, 512, SEED["cid"] + gi)
+            return ref, wl.distort(ref, wl.STANDARD_QUALITIES[qi]), 512, 512, c
+        ref = wl.make_reference(512, 512, SEED["dense"] + gi)
+        return ref, wl.distort(ref, wl.DENSE_QUALITIES[qi], bool(v & 1)), 512, 512, (c.with_xyb_roundtrip() if v >> 1 else c)
+
+
+class Resident:
+    """The workload's batches on the device: one context (= one HIP stream family) per batch so that their kernel chains
+    overlap; `depth` copies of a small grid (step k + 1 runs on the other copy while step k's scores are collected, the way
+    a session streams a corpus larger than one batch).  Every timed step's scores are collected inside the timed region."""
+
+    def __init__(self, ce, wkl, device, depth):
+        self.sets = []
+        for _ in range(depth):
+            bs = []
+            for g, c, group in wkl.launches:
+                ctx = ce.Context(device)
+                b = ce.Batch(ctx, g.width, g.height, len(g.references), len(g.pairs))
+                for i, r in enumerate(g.references):
+                    b.set_reference(i, r)
+                for k, (ri, t) in enumerate(g.pairs):
+                    b.set_test(k, ri, t)
+                bs.append((g, c, ctx, b, group))
+            self.sets.append(bs)
+        self.depth = depth
+        self.ctxs = [ctx for bs in self.sets for (_, _, ctx, _, _) in bs]
+        for bs in self.sets:  # lazy device allocations and host-built work lists are part of setting a batch up, not of a step
+            for g, c, _, b, _ in bs:
+                b.launch(len(g.pairs), c)
+                b.collect(len(g.pairs))
+
+    def run(self, n_steps, inflight, only_cfg=None, serial=False):
+        """n_steps passes over the grid; returns the scores of the last pass, one list per batch of a set."""
+        last = {}
+        if serial or inflight <= 0:  # one batch at a time, collected before the next is launched: nothing overlaps
+            for k in range(n_steps):
+                for j, (g, c, _, b, _) in enumerate(self.sets[0]):
+                    b.launch(len(g.pairs), only_cfg or c)
+                    last[j] = b.collect(len(g.pairs))
+            return [last[j] for j in sorted(last)]
+        q = collections.deque()
+        for k in range(n_steps):
+            for j, (g, c, _, b, _) in enumerate(self.sets[k % self.depth]):
+                b.launch(len(g.pairs), only_cfg or c)
+                q.append((j, g, b))
+                while len(q) > inflight:
+                    jj, gg, bb = q.popleft()
+                    last[jj] = bb.collect(len(gg.pairs))
+        while q:
+            jj, gg, bb = q.popleft()
+            last[jj] = bb.collect(len(gg.pairs))
+        return [last[j] for j in sorted(last)]
+
+    def prof(self, on, serial=False, flt=""):
+        for c in self.ctxs:
+            c.prof_reset()
+            c.prof_filter(flt)
+            c.prof_enable(on, serial=serial)
+
+    def stats(self, first_set_only=False):
+        acc = {}
+        for c in ([ctx for _, _, ctx, _, _ in self.sets[0]] if first_set_only else self.ctxs):
+            for k, (n, ms) in c.prof_stats().items():
+                n0, ms0 = acc.get(k, (0, 0.0))
+                acc[k] = (n0 + n, ms0 + ms)
+        return acc
+
+    def close(self):
+        for bs in self.sets:
+            for _, _, ctx, b, _ in bs:
+                b.close()
+                ctx.close()
+        self.sets = []
+
+
+def read_profile_tables():
+    """The newest committed counter summaries: (traffic json, {kernel: sq row}, tag)."""
+    for tag in ("r03", "r02"):
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{tag}.json")
+        spath = os.path.join(ROOT, "profiles", f"{tag}_sq_util.csv")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f)
+            sq = {}
+            if os.path.exists(spath):
+                with open(spath) as f:
+                    sq = {r["Kernel"]: r for r in csv.DictReader(f)}
+            return traffic, sq, tag
+    return {}, {}, None
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
 
     import numpy as np
-    import torch
-
-    import codec_eval_amd as ce
 
     wl = importlib.import_module("codec-eval_amd.workloads")
     sh = importlib.import_module("codec-eval_amd.sharding")
     rf = importlib.import_module("codec-eval_amd.roofline")
+    import codec_eval_amd as ce  # loads the library; no HIP call until a context is made
+
+    # ---- the workload, generated by a fork pool BEFORE anything initialises HIP in this process ---------------------------
+    wl.set_generation_workers(max(2, min(16, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
+    t_gen = time.perf_counter()
+    wkl = Workload(args.config, args, rank, world, ce, wl, sh)
+    strong_wkl = None
+    if world > 1 and args.config == 0 and not args.no_strong:
+        strong_wkl = Workload(4, args, rank, world, ce, wl, sh, as_strong=True)
+    t_gen = time.perf_counter() - t_gen
+    wl.set_generation_workers(0)
+
+    import torch
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
-    # CE_BENCH_SHARE_DEVICE=1 (rehearsal of the N > 1 path on a box with fewer GPUs than ranks): ranks share devices
-    # and the rendezvous uses gloo.  Never set by the driver.
-    share = os.environ.get("CE_BENCH_SHARE_DEVICE") == "1"
-    if share:
+    # CE_BENCH_SHARE_DEVICE=1 (rehearsal of the N > 1 path on a box with fewer GPUs than ranks): ranks share devices.
+    # Never set by the driver.
+    if os.environ.get("CE_BENCH_SHARE_DEVICE") == "1":
         local_rank = local_rank % torch.cuda.device_count()
     # 8 ranks x 16 hardware queues on ONE device is the oversubscribed regime (DESIGN.md §4); with one rank per GPU each
     # process owns its device's queues, so 16 per rank is the same setting as N = 1
     torch.cuda.set_device(local_rank)
     dist = None
-    gloo = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-            gloo = dist.group.WORLD
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            gloo = dist.new_group(backend="gloo")  # host-side gather of the score lists (python objects)
+        dist.init_process_group("gloo")  # control plane only, host side: north_star has no RCCL collective anywhere
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- the global grid and this rank's shard of it (synthetic, seeded by GLOBAL index) -----------------------
-    cfg_id = args.config
-    qualities = (75, 85, 95)  # codec-iter "quick" preset, crates/codec-iter/src/main.rs:197
-    scaling = "weak"
-    partition_mode = "reference"
-    launches_cfg = []  # [(grid, MetricConfig)] of this rank: one resident batch each
-    if cfg_id in (0, 2):
-        shapes_all = wl.kodak_corpus_shapes(world) if not args.one_shape else [(768, 512)] * (24 * world)
-        ids = [g for g in range(24 * world) if not args.quick or g % 24 in (0, 1, 2, 3, 4, 18)]  # --quick: 5 + 1 per set
-        shapes = [shapes_all[g] for g in ids]
-        pix = [w * h for (w, h) in shapes]
-        mode, units, loads = sh.plan_partition(pix, [len(qualities)] * len(pix), 1, world)
-        mine = sorted({ids[i] for i, _ in units[rank]})
-        grids = (wl.kodak_corpus_shard(mine, qualities, seed0=1000) if not args.one_shape else
-                 [wl._grid("kodak-768x512", 768, 512, 0, 1000, qualities, only=mine)])
-        cfg = ce.MetricConfig.perceptual() if cfg_id == 0 else ce.MetricConfig.ssimulacra2_only()
-        launches_cfg = [(g, cfg) for g in grids]
-        n_global_refs = len(ids)
-        what = "SSIMULACRA2 + DSSIM + Butteraugli on every pair" if cfg_id == 0 else "SSIMULACRA2 only"
-        workload = (f"BASELINE configs[1] grid: Kodak-24 x 3 quality levels (q75/85/95; 768x512 x18 + 512x768 x6 buffers) per GPU, {what}"
-                    + (f"; global grid = {world} Kodak-24 sets partitioned by reference" if world > 1 else ""))
-    elif cfg_id == 3:
-        n = args.refs or 4
-        pix = [3840 * 2160] * (n * world)
-        mode, units, loads = sh.plan_partition(pix, [1] * len(pix), 1, world)
-        mine = sorted({i for i, _ in units[rank]})
-        cfg = ce.MetricConfig(butteraugli=True)
-        launches_cfg = [(wl.uhd_pairs(n * world, seed0=2000, only=mine), cfg)]
-        n_global_refs = n * world
-        workload = f"BASELINE configs[2]: {n} synthetic 3840x2160 pairs per GPU (the config names 16: --refs 16), Butteraugli (max-norm + 3-norm)"
-    elif cfg_id == 4:
-        n = args.refs or 250
-        scaling = "strong"
-        pix = [512 * 512] * n
-        mode, units, loads = sh.plan_partition(pix, [len(wl.STANDARD_QUALITIES)] * n, 1, world)
-        mine = sorted({i for i, _ in units[rank]})
-        cfg = ce.MetricConfig(ssimulacra2=True, dssim=True)
-        launches_cfg = [(wl.cid22_like(n, seed0=3000, only=mine), cfg)]
-        n_global_refs = n
-        workload = f"BASELINE configs[3]: {n} CID22-shaped 512x512 refs x 8 qualities = {8 * n} pairs (fixed grid, partitioned by reference), SSIMULACRA2 + DSSIM"
-    else:
-        n = args.refs or 15
-        scaling = "strong"
-        pix = [512 * 512] * n
-        # codec configs of crates/codec-iter/src/main.rs:474-499: {4:4:4, 4:2:0} x {XYB off, on}; variant v = 2 * xyb + s420
-        mode, units, loads = sh.plan_partition(pix, [4 * len(wl.DENSE_QUALITIES)] * n, 4, world)
-        for xyb in (0, 1):
-            u = sorted((i, v & 1) for i, v in units[rank] if (v >> 1) == xyb)
-            if u:
-                c = ce.MetricConfig.all()
-                launches_cfg.append((wl.codec_iter_dense(n, seed0=4000, units=u), c.with_xyb_roundtrip() if xyb else c))
-        cfg = ce.MetricConfig.all()
-        n_global_refs = n
-        workload = (f"BASELINE configs[4]: {n} 512x512 refs x 25 qualities x {{4:4:4, 4:2:0}} x {{XYB off, on}} = {100 * n} pairs "
-                    f"(fixed grid), PSNR + SSIMULACRA2 + DSSIM + Butteraugli, XYB roundtrip on the reference for the XYB-on half")
-    partition_mode = mode
-    metrics_on = [m for m in METRIC_NAMES if getattr(cfg, m)]
-    # (pair, metric) evaluations per pair: the three perceptual metrics BASELINE's metric names; PSNR rides along for free
-    # (6 B/px) and is NOT counted, except in a PSNR-only configuration
-    n_eval_metrics = len([m for m in metrics_on if m != "psnr"]) or 1
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # ---- resident batches ----------------------------------------------------------------------------------------
-    # One context (= one HIP stream family) per batch, so the buckets' kernel chains overlap on the GPU.  depth > 1 keeps
-    # that many sets of batches in flight (step k is launched before step k-1's scores are collected, the way a session
-    # streams a corpus larger than one batch); every timed step's scores are still collected inside the timed region.
-    depth = 1 if args.serial else (args.depth if args.depth > 0 else 2)
-    sets = []
-    for _ in range(depth):
-        bs = []
-        for g, c in launches_cfg:
-            ctx = ce.Context(local_rank)
-            b = ce.Batch(ctx, g.width, g.height, len(g.references), len(g.pairs))
-            for i, r in enumerate(g.references):
-                b.set_reference(i, r)
-            for k, (ri, t) in enumerate(g.pairs):
-                b.set_test(k, ri, t)
-            bs.append((g, c, ctx, b))
-        sets.append(bs)
-    all_ctxs = [ctx for bs in sets for (_, _, ctx, _) in bs]
-    pairs_per_step = sum(len(g.pairs) for g, _ in launches_cfg)
-    mp_per_step = sum(g.megapixels for g, _ in launches_cfg)
-
-    def launch(k, only_cfg=None):
-        for g, c, _, b in sets[k % depth]:
-            b.launch(len(g.pairs), only_cfg or c)
-
-    def collect(k):
-        return [b.collect(len(g.pairs)) for g, _, _, b in sets[k % depth]]
-
-    def run_steps(n, only_cfg=None):
-        out = None
-        if args.serial:  # one batch at a time, collected before the next is launched: nothing overlaps, across contexts either
-            for k in range(n):
-                out = []
-                for g, c, _, b in sets[0]:
-                    b.launch(len(g.pairs), only_cfg or c)
-                    out.append(b.collect(len(g.pairs)))
-            return out
-        for k in range(n):
-            launch(k, only_cfg)
-            if k >= depth - 1:
-                out = collect(k - (depth - 1))
-        for k in range(max(0, n - (depth - 1)), n):
-            out = collect(k)
-        return out
-
-    def prof_all(on, serial=False, flt=""):
-        for c in all_ctxs:
+    def timed(res, steps, warmup, inflight, serial=False):
+        res.run(warmup, inflight, serial=serial)
+        for c in res.ctxs:
             c.prof_reset()
-            c.prof_filter(flt)
-            c.prof_enable(on, serial=serial)
+        barrier()
+        t0 = time.perf_counter()
+        scores = res.run(steps, inflight, serial=serial)
+        barrier()
+        local = time.perf_counter() - t0
+        return scores, local, max_over_ranks(local)
 
-    def gather_stats(ctxs=None):
-        acc = {}
-        for c in ctxs or all_ctxs:
-            for k, (n, ms) in c.prof_stats().items():
-                n0, ms0 = acc.get(k, (0, 0.0))
-                acc[k] = (n0 + n, ms0 + ms)
-        return acc
+    def gather_and_check(wk, res, scores):
+        """Scores of the last step in global order on rank 0; one item of every other rank is recomputed there."""
+        info = [None] * world
+        dist.all_gather_object(info, (wk.mp_per_step, wk.pairs_per_step))
+        local = []
+        for (g, c, _, _, group), sc in zip(res.sets[0], scores):
+            for pid, s in zip(g.pair_ids, sc):
+                local.append((wk.key(group, c, pid), (s.dssim, s.ssimulacra2, s.butteraugli, s.psnr)))
+        merged = [None] * world if rank == 0 else None
+        dist.gather_object(local, merged, dst=0)
+        all_mp, all_pairs = [x[0] for x in info], [x[1] for x in info]
+        if rank != 0:
+            return all_mp, all_pairs, None
+        flat = sorted((t for part in merged for t in part), key=lambda t: t[0])
+        keys = [k for k, _ in flat]
+        assert len(set(keys)) == len(keys) == sum(all_pairs), "the shards must tile the global grid exactly once"
+        foreign = {k: v for r in range(1, world) for k, v in merged[r][:1]}
+        max_diff = 0.0
+        with ce.Context(local_rank) as cx:  # single-pair call; batch == single is bit-exact
+            for key, want in foreign.items():
+                ref, test, w_, h_, c1 = wk.regenerate(key, wl, world)
+                m = cx.calculate_metrics(ref, test, w_, h_, c1)
+                got = (m.dssim or 0.0, m.ssimulacra2 or 0.0, m.butteraugli or 0.0, m.psnr or 0.0)
+                max_diff = max(max_diff, max(abs(a - b) for a, b in zip(got, want)))
+        assert max_diff == 0.0, f"a gathered score differs from its recomputation on rank 0 ({max_diff})"
+        return all_mp, all_pairs, {"partition": wk.mode, "pairs_per_rank": all_pairs, "megapixels_per_rank": [round(x, 3) for x in all_mp],
+                                   "imbalance_max_over_mean": round(sh.imbalance(all_mp), 4), "gathered_scores": len(flat),
+                                   "recomputed_on_rank0": len(foreign), "recomputed_max_abs_diff": max_diff}
 
-    # one untimed pass over every set of batches first: lazy device allocations and the host-built work lists are part
-    # of setting a batch up, not of a step
-    for bs in sets:
-        for g, c, _, b in bs:
-            b.launch(len(g.pairs), c)
-            b.collect(len(g.pairs))
+    # ---- resident batches -----------------------------------------------------------------------------------------------------
+    small = wkl.mp_per_step * wkl.n_eval_metrics < 1000.0
+    depth = 1 if args.serial else (args.depth if args.depth > 0 else (2 if small else 1))
+    res = Resident(ce, wkl, local_rank, depth)
+    n_b = len(wkl.launches)
+    inflight = args.inflight if args.inflight > 0 else ((depth * n_b - 1) if small else 3)
+    inflight = max(0, min(inflight, depth * n_b - 1))
 
-    # ---- algorithmic bytes of every kernel for one step of this rank's grid (codec-eval_amd/roofline.py) ----------
-    alg = {}
-    for g, c in launches_cfg:
-        part = rf.step_bytes([rf.Bucket(g.width, g.height, len(g.references), len(g.pairs))],
-                             [m for m in METRIC_NAMES if getattr(c, m)], c.xyb_roundtrip)
-        for k, v in part.items():
+    # ---- algorithmic bytes of every kernel for one step of this rank's grid (codec-eval_amd/roofline.py) -----------------------
+    alg, alg_r02 = {}, 0.0
+    for g, c, _ in wkl.launches:
+        bk = [rf.Bucket(g.width, g.height, len(g.references), len(g.pairs))]
+        ms_on = [m for m in METRIC_NAMES if getattr(c, m)]
+        for k, v in rf.step_bytes(bk, ms_on, c.xyb_roundtrip).items():
             alg[k] = alg.get(k, 0.0) + v
+        alg_r02 += rf.step_bytes_r02_model(bk, ms_on, c.xyb_roundtrip)
     step_alg_bytes = sum(alg.values())
 
-    # ---- solo pass (untimed): every kernel alone on the GPU, one stream, HIP events around each launch ------------
-    solo = {}
-    solo_steps = 0
+    # ---- solo pass (untimed): every kernel alone on the GPU, one stream, HIP events around each launch ---------------------------
+    solo, solo_steps = {}, 0
     if not args.no_solo:
-        solo_steps = max(3, min(10, args.steps))
-        prof_all(True, serial=True)
-        for _ in range(solo_steps):
-            for g, c, _, b in sets[0]:
-                b.launch(len(g.pairs), c)
-                b.collect(len(g.pairs))
-        solo = gather_stats([ctx for _, _, ctx, _ in sets[0]])
-        prof_all(False)
+        solo_steps = max(3, min(10, args.steps)) if small else 3
+        res.prof(True, serial=True)
+        res.run(solo_steps, 0, serial=True)
+        solo = res.stats(first_set_only=True)
+        res.prof(False)
     # dominant kernel = the one the GPU spends the most time in (solo time per step), among the kernels that move data
-    dominant = None
-    if solo:
-        dominant = max((k for k in solo if k in alg), key=lambda k: solo[k][1], default=None)
+    dominant = max((k for k in solo if k in alg), key=lambda k: solo[k][1], default=None) if solo else None
 
-    # ---- timed region -----------------------------------------------------------------------------------------------
+    # ---- timed region ---------------------------------------------------------------------------------------------------------------
     events = not args.no_events
     if args.serial:
-        prof_all(True, serial=True)
+        res.prof(True, serial=True)
     elif events:
-        prof_all(True, serial=False, flt="" if (args.all_events or dominant is None) else "=" + dominant)
-    run_steps(args.warmup)
-    for c in all_ctxs:
-        c.prof_reset()
+        res.prof(True, serial=False, flt="" if (args.all_events or dominant is None) else "=" + dominant)
+    scores, local_elapsed, elapsed = timed(res, args.steps, args.warmup, inflight, serial=args.serial)
+    in_region = res.stats() if (events or args.serial) else {}
+    res.prof(False)
 
-    barrier()
-    t0 = time.perf_counter()
-    scores = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    local_elapsed = elapsed
+    shard = None
+    all_mp, all_pairs = [wkl.mp_per_step], [wkl.pairs_per_step]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    in_region = gather_stats() if (events or args.serial) else {}
-    prof_all(False)
-
+        secs = [None] * world
+        dist.all_gather_object(secs, round(local_elapsed, 4))
+        all_mp, all_pairs, shard = gather_and_check(wkl, res, scores)
+        if shard is not None:
+            shard["seconds_per_rank"] = secs
     # SURVEY.md §8(d): MP/s = reference pixels x (pair, metric) evaluations / wall time
-    all_mp = [mp_per_step]
-    all_pairs = [pairs_per_step]
-    if dist is not None:
-        info = [None] * world
-        dist.all_gather_object(info, (mp_per_step, pairs_per_step, local_elapsed), group=gloo)
-        all_mp = [x[0] for x in info]
-        all_pairs = [x[1] for x in info]
-        all_elapsed = [x[2] for x in info]
-    else:
-        all_elapsed = [local_elapsed]
-    total_mp = sum(all_mp) * n_eval_metrics * args.steps
-    value = total_mp / elapsed
+    value = sum(all_mp) * wkl.n_eval_metrics * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- gather the scores of the last step in global order; rank 0 recomputes a sample ---------------------------
-    shard = None
-    if world > 1:
-        local = []
-        for (g, c, _, _), sc in zip(sets[(args.steps - 1) % depth], scores):
-            for pid, s in zip(g.pair_ids, sc):
-                key = (pid[0], pid[1] + (2 if c.xyb_roundtrip and cfg_id == 5 else 0), pid[2])
-                local.append((key, (s.dssim, s.ssimulacra2, s.butteraugli, s.psnr)))
-        merged = [None] * world if rank == 0 else None
-        dist.gather_object(local, merged, dst=0, group=gloo)
-        if rank == 0:
-            flat = sorted((t for part in merged for t in part), key=lambda t: t[0])
-            keys = [k for k, _ in flat]
-            assert len(set(keys)) == len(keys) == sum(all_pairs), "the shards must tile the global grid exactly once"
-            # recompute one item of every other rank's shard here (single-pair call; batch == single is bit-exact)
-            foreign = {}
-            for r in range(1, world):
-                for k, v in merged[r][:1]:
-                    foreign[k] = v
-            max_diff = 0.0
-            with ce.Context(local_rank) as cx:
-                for (gi, v, qi), want in foreign.items():
-                    if cfg_id in (0, 2):
-                        w_, h_ = wl.kodak_corpus_shapes(world)[gi]
-                        ref = wl.make_reference(w_, h_, 1000 + gi)
-                        test = wl.distort(ref, qualities[qi])
-                        c1 = cfg
-                    elif cfg_id == 3:
-                        w_, h_ = 3840, 2160
-                        ref = wl.make_reference(w_, h_, 2000 + gi)
-                        test = wl.distort(ref, 85)
-                        c1 = cfg
-                    elif cfg_id == 4:
-                        w_, h_ = 512, 512
-                        ref = wl.make_reference(w_, h_, 3000 + gi)
-                        test = wl.distort(ref, wl.STANDARD_QUALITIES[qi])
-                        c1 = cfg
-                    else:
-                        w_, h_ = 512, 512
-                        ref = wl.make_reference(w_, h_, 4000 + gi)
-                        test = wl.distort(ref, wl.DENSE_QUALITIES[qi], bool(v & 1))
-                        c1 = cfg.with_xyb_roundtrip() if v >> 1 else cfg
-                    m = cx.calculate_metrics(ref, test, w_, h_, c1)
-                    got = (m.dssim or 0.0, m.ssimulacra2 or 0.0, m.butteraugli or 0.0, m.psnr or 0.0)
-                    max_diff = max(max_diff, max(abs(a - b) for a, b in zip(got, want)))
-            shard = {
-                "partition": partition_mode, "pairs_per_rank": all_pairs, "megapixels_per_rank": [round(x, 3) for x in all_mp],
-                "imbalance_max_over_mean": round(sh.imbalance(all_mp), 4), "seconds_per_rank": [round(x, 4) for x in all_elapsed],
-                "gathered_scores": len(flat), "recomputed_on_rank0": len(foreign), "recomputed_max_abs_diff": max_diff,
-            }
-            assert max_diff == 0.0, f"a gathered score differs from its recomputation on rank 0 ({max_diff})"
-
-    # ---- roofline -----------------------------------------------------------------------------------------------------
+    # ---- roofline -----------------------------------------------------------------------------------------------------------------
     roofline = None
     if rank == 0:
         peak = rf.HBM_PEAK_GBPS
+        traffic_tbl, sq_tbl, prof_tag = read_profile_tables()
         kernels_tbl = {}
         for k in sorted(set(solo) | set(in_region)):
             row = {"metric": rf.metric_of(k)}
@@ -378,28 +478,35 @@ def main():
             if k in in_region:
                 n, ms = in_region[k]
                 row.update(in_region_ms_per_step=round(ms / args.steps, 4))
+            if k in sq_tbl:
+                row.update(valu_util=float(sq_tbl[k]["valu_util"]), waves_per_simd=float(sq_tbl[k]["waves_per_simd"]))
+            if isinstance(traffic_tbl.get(k), dict) and traffic_tbl[k].get("traffic_over_algorithmic") is not None:
+                row.update(traffic_over_algorithmic=traffic_tbl[k]["traffic_over_algorithmic"])
             kernels_tbl[k] = row
         name = dominant or (max((k for k in in_region if k in alg), key=lambda k: in_region[k][1], default=None))
         if name is not None:
-            traffic = None  # HBM bytes per launch from the PMC counters (profiles/traffic_r02.json; separate --pmc passes)
-            tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
-            px0 = sum(len(g.pairs) * g.width * g.height for g, _ in launches_cfg)
+            px0 = sum(len(g.pairs) * g.width * g.height for g, _, _ in wkl.launches)
             lps = (solo[name][0] / solo_steps) if name in solo else (in_region[name][0] / args.steps)
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    rec = json.load(f).get(name)
-                if rec:
-                    traffic = rec["bytes_per_scale0_pixel"] * px0 / lps
+            rec = traffic_tbl.get(name)
+            traffic = rec["bytes_per_scale0_pixel"] * px0 / lps if isinstance(rec, dict) else None  # HBM bytes per launch, PMC counters
             bytes_per_launch = alg[name] / lps
-            roofline = {"bound": "hbm", "kernel": name, "peak": peak, "unit": "GB/s", "traffic": traffic,
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": lps}
+            sq = sq_tbl.get(name)
+            valu = float(sq["valu_util"]) if sq else None
+            # the roof that binds the kernel: the vector ALUs when the SQ counters say they are busy most of the time
+            roofline = {"bound": "valu" if (valu is not None and valu >= 0.6) else "hbm", "kernel": name, "peak": peak, "unit": "GB/s",
+                        "traffic": traffic, "algorithmic_bytes_per_launch": bytes_per_launch, "launches_per_step": lps,
+                        "valu_util": valu, "waves_per_simd": float(sq["waves_per_simd"]) if sq else None,
+                        "counters_from": f"profiles/traffic_{prof_tag}.json, profiles/{prof_tag}_sq_util.csv (768x512 bucket of the Kodak grid: 54 pairs, 18 references)" if prof_tag else None,
+                        "bound_note": "achieved / peak / frac are the HBM figures the contract defines (algorithmic bytes over the launch's duration "
+                                      "against 8 TB/s); `bound` names the roof the SQ counters show the kernel at: valu = SQ_ACTIVE_INST_VALU over "
+                                      "the SIMD cycles of the launch >= 0.6"}
             if name in solo:
                 n, ms = solo[name]
                 avg = ms / n * 1e-3
                 roofline.update(achieved=round(bytes_per_launch / avg / 1e9, 1), frac=round(bytes_per_launch / avg / 1e9 / peak, 4),
                                 avg_launch_ms=round(avg * 1e3, 4), launches=n,
                                 frac_basis="solo: the launch alone on the GPU, HIP events on its stream, untimed pass of this same run "
-                                           "(in the timed region the metrics' chains, shape buckets and steps overlap, so a launch's "
+                                           "(in the timed region the metrics' chains, batches and steps overlap, so a launch's "
                                            "duration there is its share of the GPU - see in_region_*)")
             if name in in_region:
                 n, ms = in_region[name]
@@ -413,44 +520,73 @@ def main():
                 elif name in solo:
                     roofline["in_region_share"] = round((solo[name][1] / solo[name][0]) / (ms / n), 3)
             solo_total = sum(ms for _, ms in solo.values()) / solo_steps if solo else None
+            # whole step, counters vs counts: kernels of the profiled bucket weighted by their share of this step's algorithmic bytes
+            num = sum(alg[k] * traffic_tbl[k]["traffic_over_algorithmic"] for k in alg
+                      if isinstance(traffic_tbl.get(k), dict) and traffic_tbl[k].get("traffic_over_algorithmic"))
+            den = sum(alg[k] for k in alg if isinstance(traffic_tbl.get(k), dict) and traffic_tbl[k].get("traffic_over_algorithmic"))
             roofline.update(
                 dominant_by="largest solo time per step (%.0f %% of the step's kernel time)" % (100.0 * solo[name][1] / max(sum(ms for _, ms in solo.values()), 1e-12)) if name in solo else "largest in-region time",
-                # all kernels of the step against the same peak
+                # all kernels of the step against the same peak, on this round's byte model and on round 2's frozen one
                 pipeline_algorithmic_bytes_per_step=step_alg_bytes,
                 pipeline_achieved=round(step_alg_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                 pipeline_frac=round(step_alg_bytes / (ms_per_step * 1e-3) / 1e9 / peak, 4),
+                pipeline_r02_model_bytes_per_step=alg_r02,
+                pipeline_frac_r02_model=round(alg_r02 / (ms_per_step * 1e-3) / 1e9 / peak, 4),
+                traffic_over_algorithmic=round(num / den, 3) if den else None,
                 solo_kernel_ms_per_step=round(solo_total, 4) if solo_total else None,
-                bytes_model="codec-eval_amd/roofline.py: compulsory bytes of each kernel (inputs once, outputs once; reference-side "
-                            "inputs once per reference); SURVEY.md §8(d)'s uncached-pair stage sums would be "
-                            + ", ".join(f"{m} {rf.uncached_pair_bytes_per_px0(m):.0f}" for m in metrics_on) + " B per scale-0 pixel",
+                bytes_model="codec-eval_amd/roofline.py step_bytes(): compulsory bytes of each kernel (inputs once, outputs once; reference-side "
+                            "inputs once per reference); step_bytes_r02_model(): the same rule on round 2's kernels, frozen; SURVEY.md §8(d)'s "
+                            "uncached-pair stage sums would be " + ", ".join(f"{m} {rf.uncached_pair_bytes_per_px0(m):.0f}" for m in wkl.metrics_on)
+                            + " B per scale-0 pixel",
                 kernels=kernels_tbl,
             )
 
-    # ---- per-metric breakdown: each metric alone on the same resident grid (rank 0 prints; every rank runs) ---------
+    # ---- per-metric breakdown: each metric alone on the same resident grid (N = 1) ---------------------------------------------------
     per_metric = None
-    if not args.no_per_metric and len(metrics_on) > 1 and world == 1:
+    if not args.no_per_metric and len(wkl.metrics_on) > 1 and world == 1:
         per_metric = {}
-        for m in metrics_on:
+        for m in wkl.metrics_on:
             one = ce.MetricConfig(**{m: True})
-            if cfg.xyb_roundtrip:
+            if wkl.cfg.xyb_roundtrip:
                 one = one.with_xyb_roundtrip()
-            n = max(3, min(args.steps, 20))
-            run_steps(2, one)
+            n = max(3, min(args.steps, 20)) if small else 3
+            res.run(1, inflight, one)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(n, one)
+            res.run(n, inflight, one)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            per_metric[m] = {"value": round(mp_per_step * n / dt, 2), "unit": "MP/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n}
-        # restore the combined working state (scores of the combined config) for the checks below
-        scores = run_steps(1)
+            per_metric[m] = {"value": round(wkl.mp_per_step * n / dt, 2), "unit": "MP/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n}
+        scores = res.run(1, inflight)  # the combined config's scores again, for the checks below
 
-    # ---- end to end: page-locked host buffers in, scores out (uploads inside the timing) -----------------------------
-    end_to_end = None
+    # ---- the oracle's values for a bounded sample of the grid + the CPU baseline (rank 0, N = 1 only) ----------------------------------
+    cpu_baseline, max_dev = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline, max_dev = run_cpu_baseline(wkl, res, scores, np)
+
+    launches_main = wkl.launches
+    kodak_only, end_to_end, per_call, strong = None, None, None, None
+    res.close()
+
+    # ---- Kodak grid alone: rounds 1-2's headline, for continuity (config 0, N = 1) ------------------------------------------------------
+    kodak_launches = [l for l in launches_main if l[2] == "kodak"]
+    if args.config == 0 and world == 1 and kodak_launches and len(kodak_launches) < len(launches_main):
+        kw = Workload.__new__(Workload)
+        kw.__dict__.update(wkl.__dict__)
+        kw.launches = kodak_launches
+        kw.mp_per_step = sum(g.megapixels for g, _, _ in kodak_launches)
+        kres = Resident(ce, kw, local_rank, 2)
+        n = max(args.steps, 20)
+        _, _, dt = timed(kres, n, max(args.warmup, 3), 2 * len(kodak_launches) - 1)
+        kodak_only = {"value": round(kw.mp_per_step * wkl.n_eval_metrics * n / dt, 2), "unit": "MP/s", "ms_per_step": round(dt / n * 1e3, 4), "steps": n,
+                      "workload": "BASELINE configs[1] grid alone (72 pairs: Kodak-24 x q75/85/95), the three metrics: BENCH_r01 / r02's headline"}
+        kres.close()
+
+    # ---- end to end: page-locked host buffers in, scores out (uploads inside the timing; Kodak part of the grid) ------------------------
     if not args.no_end_to_end and world == 1 and rank == 0:
-        items = []
-        keep = []
-        for g, c in launches_cfg:
+        e2e_l = kodak_launches or launches_main[:1]
+        items, keep = [], []
+        for g, c, _ in e2e_l:
             refs_p = []
             for r in g.references:
                 t = torch.empty(r.size, dtype=torch.uint8).pin_memory()
@@ -465,6 +601,7 @@ def main():
         by_cfg = {}
         for c, it in items:
             by_cfg.setdefault((c.mask, c.flags), (c, []))[1].append(it)
+        mp = sum(g.megapixels for g, _, _ in e2e_l)
         with ce.Context(local_rank) as cx:
             def e2e_step():
                 for c, its in by_cfg.values():
@@ -475,81 +612,56 @@ def main():
             for _ in range(n):
                 e2e_step()
             dt = time.perf_counter() - t1
-        end_to_end = {"value": round(mp_per_step * n_eval_metrics * n / dt, 2), "unit": "MP/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
+        end_to_end = {"value": round(mp * wkl.n_eval_metrics * n / dt, 2), "unit": "MP/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
+                      "grid": "the Kodak part of the workload" if kodak_launches else "the first batch of the workload",
                       "route": "ce_eval_batch: page-locked host RGB8 in -> H2D on the upload stream (chunked, overlapped with the "
                                "kernels of the previous chunk) -> kernels -> scores on the host; 6 B/px over PCIe per pair "
                                "(3 B/px for the pairs that share an already uploaded reference)",
-                      "h2d_megabytes_per_step": round(sum((len(g.references) + len(g.pairs)) * g.width * g.height * 3 for g, _ in launches_cfg) / 1e6, 1)}
+                      "h2d_megabytes_per_step": round(sum((len(g.references) + len(g.pairs)) * g.width * g.height * 3 for g, _, _ in e2e_l) / 1e6, 1)}
         del keep
 
-    # ---- CPU baseline: the C oracle on this host's cores (rank 0, N = 1 only) ------------------------------------------
-    cpu_baseline = None
-    max_dev = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
+    # ---- per call: the reference's one GPU plug point is ONE blocking call per encode (crates/codec-iter/src/gpu.rs:83-109) -------------
+    if not args.no_per_call and world == 1 and rank == 0:
+        per_call = {"unit": "ms per call, median of 40 after 8 warm-up calls, nothing else on the device",
+                    "ce_eval_pair": "calculate_metrics(reference, distorted): both images uploaded, scores on the host",
+                    "ce_ref_compare": "ReferenceHandle.compare(distorted): the reference and its reference-side state resident (Ssimulacra2Reference semantics, eval.rs:138-149)"}
+        with ce.Context(local_rank) as cx:
+            for (w_, h_) in ((768, 512), (512, 512)):
+                ref = wl.make_reference(w_, h_, 77)
+                test = wl.distort(ref, 80)
+                row = {}
 
-        O.build()
-        fn = {"ssimulacra2": lambda r, t, w, h: O.ssimulacra2(r, t, w, h, 1), "dssim": O.dssim,
-              "butteraugli": lambda r, t, w, h: O.butteraugli(r, t, w, h)[0], "psnr": O.psnr}
-        flat_pairs = [(g, c, ri, t) for g, c in launches_cfg for (ri, t) in g.pairs]
-        # bounded sample: at most SAMPLE_MP megapixels of pairs (evenly spaced over the grid), every enabled metric on each
-        SAMPLE_MP = 30.0
-        mp_pair = [g.width * g.height / 1e6 for g, _, _, _ in flat_pairs]
-        stride = max(1, int(np.ceil(sum(mp_pair) / SAMPLE_MP)))
-        sample_idx = list(range(0, len(flat_pairs), stride))
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
-        # work items = (pair, metric); the slow metric first so the pool drains evenly
-        cost = {"butteraugli": 3, "dssim": 2, "ssimulacra2": 1, "psnr": 0}
-        work = sorted(((i, m) for i in sample_idx for m in metrics_on), key=lambda im: -cost[im[1]])
+                def med(fn):
+                    for _ in range(8):
+                        fn()
+                    ts = []
+                    for _ in range(40):
+                        t1 = time.perf_counter()
+                        fn()
+                        ts.append(time.perf_counter() - t1)
+                    return round(sorted(ts)[len(ts) // 2] * 1e3, 4)
+                allm, s2 = ce.MetricConfig.all(), ce.MetricConfig.ssimulacra2_only()
+                row["ce_eval_pair_all_metrics"] = med(lambda: cx.calculate_metrics(ref, test, w_, h_, allm))
+                row["ce_eval_pair_ssimulacra2"] = med(lambda: cx.calculate_metrics(ref, test, w_, h_, s2))
+                hnd = ce.ReferenceHandle(cx, ref, w_, h_)
+                row["ce_ref_compare_all_metrics"] = med(lambda: hnd.compare(test, allm))
+                row["ce_ref_compare_ssimulacra2"] = med(lambda: hnd.compare(test, s2))
+                hnd.close()
+                per_call[f"{w_}x{h_}"] = row
 
-        def one(im):
-            i, m = im
-            g, c, ri, t = flat_pairs[i]
-            ref = g.references[ri]
-            if c.xyb_roundtrip:
-                ref = O.xyb_roundtrip(ref, g.width, g.height)
-            return fn[m](ref, t, g.width, g.height)
-
-        # 1 thread: the first pair of the sample, every metric
-        one_thread = {}
-        for m in metrics_on:
-            t1 = time.perf_counter()
-            one((sample_idx[0], m))
-            one_thread[m] = round(mp_pair[sample_idx[0]] / (time.perf_counter() - t1), 3)
-        threads = max(1, min(cores, len(work)))
-        with ThreadPoolExecutor(threads) as ex:  # ctypes releases the GIL: item-level parallelism,
-            list(ex.map(one, work[:threads]))       # warm pass (page in the library on every thread)
-            tN = time.perf_counter()
-            res = list(ex.map(one, work))           # mirrors images.par_iter() (full_comparison.rs:319-328)
-            dtN = time.perf_counter() - tN
-        sample_mp = sum(mp_pair[i] for i in sample_idx)
-        cpu_baseline = {
-            "value": round(sample_mp * len(metrics_on) / dtN, 3), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": f"{len(sample_idx)} of the {len(flat_pairs)} pairs (every {stride}th), {'+'.join(metrics_on)} on each = {len(work)} "
-                      f"(pair, metric) items over a pool of {threads} threads (host has {cores} cores; pool = min(cores, items)), "
-                      f"one warm pass first; scalar C restatement of the metrics (oracle/*.c), NOT the Rust crates' SIMD code",
-            "seconds": round(dtN, 2), "host_cores": cores,
-            "value_1thread_per_metric": one_thread,
-        }
-        # the device against the same oracle values, on the sampled pairs
-        got = [s for sc in scores for s in sc]
-        want = {}
-        for (i, m), v in zip(work, res):
-            want[(i, m)] = v
-        max_dev = {}
-        for m in metrics_on:
-            floor = {"ssimulacra2": 1.0, "dssim": 1e-6, "butteraugli": 1e-3, "psnr": 1.0}[m]
-            dev = 0.0
-            for i in sample_idx:
-                a, b = getattr(got[i], m), want[(i, m)]
-                if a == b:
-                    continue
-                dev = max(dev, abs(a - b) / max(abs(b), floor))
-            max_dev[m] = dev
+    # ---- strong scaling leg (N > 1, default workload): BASELINE configs[3]'s FIXED grid over the same ranks -------------------------------
+    if strong_wkl is not None:
+        sres = Resident(ce, strong_wkl, local_rank, 1)
+        n = max(2, min(args.steps, 5))
+        sscores, slocal, sel = timed(sres, n, 1, max(0, min(3, len(strong_wkl.launches) - 1)))
+        ssecs = [None] * world
+        dist.all_gather_object(ssecs, round(slocal, 4))
+        smp, spairs, sshard = gather_and_check(strong_wkl, sres, sscores)
+        sres.close()
+        if rank == 0:
+            strong = dict(sshard, value=round(sum(smp) * strong_wkl.n_eval_metrics * n / sel, 2), unit="MP/s", steps=n,
+                          ms_per_step=round(sel / n * 1e3, 3), seconds_per_rank=ssecs, scaling="strong", workload=strong_wkl.workload,
+                          metrics=strong_wkl.metrics_on, pairs_per_step=sum(spairs), metric_evaluations_per_pair=strong_wkl.n_eval_metrics)
 
     if rank == 0:
         line = {
@@ -561,41 +673,176 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": scaling,
+            "scaling": wkl.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": workload + (" [--quick subset]" if args.quick else ""),
-                "metrics": metrics_on,
+                "workload": wkl.workload + (" [--quick subset]" if args.quick else ""),
+                "metrics": wkl.metrics_on,
                 "pairs_per_step": sum(all_pairs),
                 "megapixels_per_step": round(sum(all_mp), 3),
-                "metric_evaluations_per_pair": n_eval_metrics,
-                "sharding": f"global grid of {n_global_refs} references partitioned by {partition_mode}, one process per GPU, no collective on the data path",
+                "metric_evaluations_per_pair": wkl.n_eval_metrics,
+                "sharding": f"global grid of {wkl.n_global_refs} references partitioned by {wkl.mode}, one process per GPU, no collective on the data path",
                 "inputs": "resident in HBM (uploaded before the timed region)",
-                "batches_in_flight": depth,
+                "resident_batches": [f"{g.name}: {len(g.references)} refs x {len(g.pairs) // max(1, len(g.references))} = {len(g.pairs)} pairs" for g, _, _ in launches_main],
+                "batch_copies": depth,
+                "batches_in_flight": inflight + 1,
                 "schedule": "serial (one stream, one kernel at a time)" if args.serial else
-                            ("shape buckets and in-flight steps overlap on their own HIP streams; a batch's metric chains run "
+                            ("batches and in-flight steps overlap on their own HIP streams; a batch's metric chains run "
                              + ("as CE_METRIC_STREAMS=%s says" % os.environ["CE_METRIC_STREAMS"] if os.environ.get("CE_METRIC_STREAMS") else
                                 "back to back (side by side only for a batch of <= 4 MP of pairs or one launched while nothing else is "
                                 "in flight on the device)")),
+                "workload_generation_seconds": round(t_gen, 1),
                 "hip_env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             },
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "per_metric": per_metric,
+            "kodak_only": kodak_only,
+            "per_call": per_call,
             "end_to_end": end_to_end,
             "shard": shard,
+            "strong": strong,
             "max_rel_dev_vs_oracle": max_dev,
         }
         print(json.dumps(line), flush=True)
 
-    for bs in sets:
-        for _, _, ctx, b in bs:
-            b.close()
-            ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- CPU baseline: the C oracle on this host's cores, in worker PROCESSES, pool size swept ---------------------------------------------
+CPU_WORKER = r"""
+import sys, time, json, importlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+data = np.load(sys.argv[2])
+k, n = int(sys.argv[3]), int(sys.argv[4])
+items = json.loads(sys.argv[5])
+fn = {"ssimulacra2": lambda r, t, w, h: O.ssimulacra2(r, t, w, h, 1), "dssim": O.dssim,
+      "butteraugli": lambda r, t, w, h: O.butteraugli(r, t, w, h)[0], "psnr": O.psnr}
+def run(i, m, xyb):
+    r, t = data[f"r{i}"], data[f"t{i}"]
+    h, w = r.shape[:2]
+    if xyb:
+        r = O.xyb_roundtrip(r, w, h)
+    return fn[m](r, t, w, h)
+mine = items[k::n]
+if mine:
+    run(*mine[0])  # warm: page the library and the inputs in
+print("ready", flush=True)
+sys.stdin.readline()  # all workers start together
+t0 = time.perf_counter()
+out = [(i, m, run(i, m, x)) for i, m, x in mine]
+print(json.dumps({"seconds": time.perf_counter() - t0, "out": out}), flush=True)
+"""
+
+
+def run_cpu_baseline(wkl, res, scores, np):
+    """Worker processes (each single-threaded, its own address space: no allocator or page-fault contention between them),
+    every pool size of a sweep runs the same (pair, metric) items; the best MP/s is the baseline."""
+    from oracle import oracle as O
+
+    O.build()
+    flat_pairs = [(g, c, ri, t) for g, c, _ in wkl.launches for (ri, t) in g.pairs]
+    # bounded sample: at most SAMPLE_MP megapixels of pairs (evenly spaced over the grid), every enabled metric on each
+    SAMPLE_MP = 24.0
+    mp_pair = [g.width * g.height / 1e6 for g, _, _, _ in flat_pairs]
+    stride = max(1, int(np.ceil(sum(mp_pair) / SAMPLE_MP)))
+    sample_idx = list(range(0, len(flat_pairs), stride))
+    cores = host_cpus()
+    cost = {"butteraugli": 3, "dssim": 2, "ssimulacra2": 1, "psnr": 0}  # the slow metric first so a pool drains evenly
+    items = sorted(((i, m, bool(flat_pairs[i][1].xyb_roundtrip)) for i in sample_idx for m in wkl.metrics_on), key=lambda im: -cost[im[1]])
+    tmp = tempfile.mkdtemp(prefix="ce_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(tmp, "sample.npz")
+    arrs = {}
+    for i in sample_idx:
+        g, c, ri, t = flat_pairs[i]
+        arrs[f"r{i}"], arrs[f"t{i}"] = g.references[ri], t
+    np.savez(path, **arrs)
+    sample_mp = sum(mp_pair[i] for i in sample_idx)
+
+    def pool(n):
+        ps = [subprocess.Popen([sys.executable, "-c", CPU_WORKER, ROOT, path, str(k), str(n), json.dumps(items)], stdin=subprocess.PIPE,
+                               stdout=subprocess.PIPE, text=True) for k in range(n)]
+        for p in ps:
+            assert p.stdout.readline().strip() == "ready"
+        t0 = time.perf_counter()
+        for p in ps:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        outs = [json.loads(p.stdout.readline()) for p in ps]
+        dt = time.perf_counter() - t0
+        for p in ps:
+            p.wait()
+        return dt, outs
+
+    try:
+        # 1 process, every metric on the sample's first pair
+        one_thread = {}
+        first = sample_idx[0]
+        g, c, ri, t = flat_pairs[first]
+        fn = {"ssimulacra2": lambda r, t, w, h: O.ssimulacra2(r, t, w, h, 1), "dssim": O.dssim,
+              "butteraugli": lambda r, t, w, h: O.butteraugli(r, t, w, h)[0], "psnr": O.psnr}
+        for m in wkl.metrics_on:
+            fn[m](g.references[ri], t, g.width, g.height)
+            t1 = time.perf_counter()
+            fn[m](g.references[ri], t, g.width, g.height)
+            one_thread[m] = round(mp_pair[first] / (time.perf_counter() - t1), 3)
+        combined_1 = len(wkl.metrics_on) / sum(1.0 / one_thread[m] for m in wkl.metrics_on)  # MP/s of (pair, metric) evaluations, one process
+        sweep, best, want = {}, None, {}
+        for n in sorted({min(cores, x) for x in (16, 32, 64, 128, cores)}):
+            if n > len(items):
+                continue
+            dt, outs = pool(n)
+            v = sample_mp * len(wkl.metrics_on) / dt
+            sweep[str(n)] = round(v, 2)
+            if best is None or v > best[1]:
+                best = (n, v, dt)
+            for o in outs:
+                for i, m, val in o["out"]:
+                    want[(i, m)] = val
+    finally:
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q = f.read().split()
+            quota = None if q[0] == "max" else round(int(q[0]) / int(q[1]), 1)
+    except Exception:
+        pass
+    n, v, dt = best
+    cpu_baseline = {
+        "value": round(v, 2), "unit": "MP/s", "cores": n, "kind": "port",
+        "sample": f"{len(sample_idx)} of the {len(flat_pairs)} pairs (every {stride}th), {'+'.join(wkl.metrics_on)} on each = {len(items)} "
+                  f"(pair, metric) items dealt to {n} single-threaded worker PROCESSES (mirrors images.par_iter(), full_comparison.rs:319-328; "
+                  f"pool size swept, the best is reported; each worker warm); scalar C restatement of the metrics (oracle/*.c), NOT the "
+                  f"Rust crates' SIMD code",
+        "seconds": round(dt, 2), "host_cores": cores, "cgroup_cpu_quota_cores": quota, "threads": n,
+        "pool_sweep_mp_per_s": sweep,
+        "per_thread_efficiency": round(v / (n * combined_1), 3),
+        "value_1thread_combined": round(combined_1, 3),
+        "value_1thread_per_metric": one_thread,
+    }
+    # the device against the same oracle values, on the sampled pairs
+    got = [s for sc in scores for s in sc]
+    max_dev = {}
+    for m in wkl.metrics_on:
+        floor = {"ssimulacra2": 1.0, "dssim": 1e-6, "butteraugli": 1e-3, "psnr": 1.0}[m]
+        dev = 0.0
+        for i in sample_idx:
+            a, b = getattr(got[i], m), want[(i, m)]
+            if a != b:
+                dev = max(dev, abs(a - b) / max(abs(b), floor))
+        max_dev[m] = dev
+    return cpu_baseline, max_dev
 
 
 if __name__ == "__main__":

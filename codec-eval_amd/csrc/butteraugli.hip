@@ -713,21 +713,35 @@ __device__ __forceinline__ float malta_pre_diff(float v0, float v1, const malta_
     const float diff = v0 - v1;
     float scaler, scaler2;  // norm2_0gt1 / (norm1 + absval), norm2_0lt1 / (norm1 + absval)
     div2_shared_rcp(mp.norm2_0gt1, mp.norm2_0lt1, mp.norm1 + absval, scaler, scaler2);
-    float r = scaler * diff;
-    const double fabs0 = fabs((double)v0);
-    const double too_small = 0.55 * fabs0, too_big = 1.05 * fabs0;
-    // The four branches of MaltaDiffMap's asymmetry term, without divergence.  Mirror v1 for a negative v0:
-    //   v0 <  0: v1 > -too_small  <=>  u < too_small   impact = scaler2 (v1 + too_small) = scaler2 (too_small - u),  r - impact
-    //            v1 < -too_big    <=>  u > too_big     impact = scaler2 (-v1 - too_big)  = scaler2 (u - too_big),    r + impact
-    //   v0 >= 0: v1 <  too_small  <=>  u < too_small   impact = scaler2 (too_small - v1),                             r + impact
-    //            v1 >  too_big    <=>  u > too_big     impact = scaler2 (v1 - too_big),                               r - impact
-    // with u = v0 < 0 ? -v1 : v1; every value is formed by the same f64 operations as in the branchy form.
+    const float r = scaler * diff;
+    // The four branches of MaltaDiffMap's asymmetry term, without divergence, in f32 (the lineage forms it in f64: worth
+    // 9e-8 of the score, tests/golden/sensitivity.json "ba_malta_f32" - the oracle's switch of that name is this arithmetic
+    // bit for bit; round 2 paid ten f64-rate instructions per sample for it).  Mirror v1 for a negative v0:
+    //   v0 <  0: v1 > -too_small  <=>  u < too_small   r - scaler2 (v1 + too_small) = r - scaler2 (too_small - u)
+    //            v1 < -too_big    <=>  u > too_big     r + scaler2 (-v1 - too_big)  = r + scaler2 (u - too_big)
+    //   v0 >= 0: v1 <  too_small  <=>  u < too_small   r + scaler2 (too_small - v1)
+    //            v1 >  too_big    <=>  u > too_big     r - scaler2 (v1 - too_big)
+    // with u = v0 < 0 ? -v1 : v1.
+    const float fabs0 = fabsf(v0), too_small = 0.55f * fabs0, too_big = 1.05f * fabs0;
     const bool neg = v0 < 0;
-    const double u = neg ? -(double)v1 : (double)v1;
+    const float u = neg ? -v1 : v1;
     const bool lo = u < too_small, hi = u > too_big;
-    const double impact = (double)scaler2 * (lo ? too_small - u : u - too_big);
-    const double rn = (double)r + ((neg == lo) ? -impact : impact);
-    return (lo || hi) ? (float)rn : r;
+    const float impact = scaler2 * (lo ? too_small - u : u - too_big);
+    const float rn = r + ((neg == lo) ? -impact : impact);
+    return (lo || hi) ? rn : r;
+}
+
+// L2DiffAsymmetric's in-place accumulation for one sample of hf[c] (libjxl / oracle l2_diff_asymmetric)
+__device__ __forceinline__ float l2_asym_acc(float total, float val0, float val1, float vw_0gt1, float vw_0lt1)
+{
+    const float diff = val0 - val1;
+    total = __builtin_fmaf(diff * diff, vw_0gt1, total);
+    const float fabs0 = fabsf(val0);
+    const float too_small = 0.4f * fabs0, too_big = fabs0;
+    const float if_neg = val1 > -too_small ? val1 + too_small : (val1 < -too_big ? -val1 - too_big : 0.0f);
+    const float if_pos = val1 < too_small ? too_small - val1 : (val1 > too_big ? val1 - too_big : 0.0f);
+    const float v = val0 < 0.0f ? if_neg : if_pos;
+    return __builtin_fmaf(vw_0lt1, v * v, total);
 }
 
 // Channels X and Y are PACKED: the LDS tile holds (x-diff, y-diff) pairs and a thread forms the 16 line sums of MaltaUnit
@@ -818,6 +832,8 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
     const float *b = psy + (size_t)(max_refs + p) * PSY * g.plane;
     // thread -> two adjacent outputs (columns 2*tq, 2*tq+1 of row 8*sub + ty), four row groups per tile
     const int tq = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
+    const float hf_asymmetry = 1.0f;
 #pragma unroll
     for (int band = 0; band < 3; band++) {
         const malta_params mpx = mb.p[0][band], mpy = mb.p[1][band];
@@ -848,6 +864,33 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
             float4 *dst = reinterpret_cast<float4 *>(s + ly * ML + 4 * lq);
             dst[0] = r01;
             dst[1] = r23;
+            // The HF / MF samples of the tile's OWN pixels are in registers here: their L2DiffAsymmetric (hf) / L2Diff (mf)
+            // terms join the running block_diff_ac sums now (after the previous band's Malta sums, before this band's),
+            // instead of being loaded again - 32 B per pixel - by the epilogue.  The same in-place accumulations as the
+            // lineage's, in another order: the oracle's switch "ba_l2_early" is this order bit for bit.
+            if (band >= 1 && ly >= MH && ly < MH + MR && lq >= MH / 4 && lq < (MH + MT) / 4 && gy < (int)g.h) {
+                float4 *pa = reinterpret_cast<float4 *>(s_acc + (ly - MH) * MT + 4 * lq - MH);
+                float4 t01 = pa[0], t23 = pa[1];  // (x0, y0, x1, y1), (x2, y2, x3, y3)
+                if (band == 1) {
+                    const float gx_ = wmul[0] * hf_asymmetry * 0.8f, lx_ = wmul[0] / hf_asymmetry * 0.8f;
+                    const float gy_ = wmul[1] * hf_asymmetry * 0.8f, ly_ = wmul[1] / hf_asymmetry * 0.8f;
+                    if (i0) t01.x = l2_asym_acc(t01.x, vax.x, vbx.x, gx_, lx_), t01.y = l2_asym_acc(t01.y, vay.x, vby.x, gy_, ly_);
+                    if (i1) t01.z = l2_asym_acc(t01.z, vax.y, vbx.y, gx_, lx_), t01.w = l2_asym_acc(t01.w, vay.y, vby.y, gy_, ly_);
+                    if (i2) t23.x = l2_asym_acc(t23.x, vax.z, vbx.z, gx_, lx_), t23.y = l2_asym_acc(t23.y, vay.z, vby.z, gy_, ly_);
+                    if (i3) t23.z = l2_asym_acc(t23.z, vax.w, vbx.w, gx_, lx_), t23.w = l2_asym_acc(t23.w, vay.w, vby.w, gy_, ly_);
+                } else {
+                    auto l2 = [](float total, float v0, float v1, float w) {
+                        const float diff = v0 - v1;
+                        return __builtin_fmaf(diff * diff, w, total);
+                    };
+                    if (i0) t01.x = l2(t01.x, vax.x, vbx.x, wmul[3]), t01.y = l2(t01.y, vay.x, vby.x, wmul[4]);
+                    if (i1) t01.z = l2(t01.z, vax.y, vbx.y, wmul[3]), t01.w = l2(t01.w, vay.y, vby.y, wmul[4]);
+                    if (i2) t23.x = l2(t23.x, vax.z, vbx.z, wmul[3]), t23.y = l2(t23.y, vay.z, vby.z, wmul[4]);
+                    if (i3) t23.z = l2(t23.z, vax.w, vbx.w, wmul[3]), t23.w = l2(t23.w, vay.w, vby.w, wmul[4]);
+                }
+                pa[0] = t01;
+                pa[1] = t23;
+            }
         }
         __syncthreads();
 #pragma unroll 1
@@ -866,8 +909,6 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
         }
         __syncthreads();
     }
-    const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f, 29.2353797994f, 0.844626970982f, 0.703646627719f};
-    const float hf_asymmetry = 1.0f;
     float red_m = 0.0f;  // the diffmap is non-negative
     double red_s3 = 0.0, red_s6 = 0.0, red_s12 = 0.0;
 #pragma unroll 1
@@ -881,20 +922,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 3 : 4) void k_ba_malta_l2_xy(const 
         float acv[3], dcv[3];
 #pragma unroll
         for (uint32_t c = 0; c < 3; c++) {
+            // channels X and Y: the Malta sums of the three bands and the hf / mf L2 terms are all in `sums` (see the tile
+            // fill); channel B has no Malta term and no hf: L2Diff on mf[2] only
             float total = c == 0 ? sums.x : c == 1 ? sums.y : 0.0f;
-            if (c < 2) {  // L2DiffAsymmetric on hf[c]
-                const float vw_0gt1 = wmul[c] * hf_asymmetry * 0.8f, vw_0lt1 = wmul[c] / hf_asymmetry * 0.8f;
-                const float val0 = a[(HF0 + c) * g.plane + o], val1 = b[(HF0 + c) * g.plane + o];
-                const float diff = val0 - val1;
-                total = __builtin_fmaf(diff * diff, vw_0gt1, total);
-                const float fabs0 = fabsf(val0);
-                const float too_small = 0.4f * fabs0, too_big = fabs0;
-                const float if_neg = val1 > -too_small ? val1 + too_small : (val1 < -too_big ? -val1 - too_big : 0.0f);
-                const float if_pos = val1 < too_small ? too_small - val1 : (val1 > too_big ? val1 - too_big : 0.0f);
-                const float v = val0 < 0.0f ? if_neg : if_pos;
-                total = __builtin_fmaf(vw_0lt1, v * v, total);
-            }
-            {  // L2Diff on mf[c]
+            if (c == 2) {
                 const float diff = a[(MF0 + c) * g.plane + o] - b[(MF0 + c) * g.plane + o];
                 total = __builtin_fmaf(diff * diff, wmul[3 + c], total);
             }

@@ -150,6 +150,56 @@ def step_bytes(buckets: Iterable[Bucket], metrics: Iterable[str], xyb_roundtrip:
     return acc
 
 
+# ---- round 2's byte model, FROZEN --------------------------------------------------------------
+# As stages fuse, a kernel's compulsory bytes shrink and `pipeline_frac` falls while the step gets faster, so fractions of
+# different rounds are not comparable.  This table is round 2's model (BENCH_r02: 16.56 GB per step of the 72-pair Kodak
+# grid, all three metrics) in bytes per pixel OF THE KERNEL'S LEVEL: P = per pair, R = per reference, S = per image slot,
+# (lvl0, upper) where level 0 reads u8.  bench.py prices every round's step time against it as
+# `pipeline_frac_r02_model`; step_bytes() above is the CURRENT kernels' model.
+R02_MODEL = {
+    # name: (per-level pyramid, [(unit, bytes/px at level 0, bytes/px at levels >= 1, bytes per NEXT-level px)])
+    "ssim2_prep": ("ssim2", [("S", 3, 12, 12)]),
+    "ssim2_hblur": ("ssim2", [("P", 36 + 3, 36 + 12, 0), ("R", 24 + 3, 24 + 12, 0)]),
+    "ssim2_vblur_ssim": ("ssim2", [("P", 36 + 3, 36 + 12, 0), ("R", 24 + 3, 24 + 12, 0)]),
+    "dssim_create": ("dssim", [("S", 3, 12, 12), ("P", 12, 12, 0), ("R", 36, 36, 0)]),
+    "dssim_compare": ("dssim", [("P", 16, 16, 0), ("R", 36, 36, 0)]),
+    "dssim_absdev": ("dssim", [("P", 4, 4, 0)]),
+}
+
+
+def step_bytes_r02_model(buckets: Iterable[Bucket], metrics: Iterable[str], xyb_roundtrip: bool = False) -> float:
+    """Bytes per step under round 2's model.  SSIMULACRA2 / DSSIM from R02_MODEL; Butteraugli's round-2 rows are exactly
+    butteraugli_bytes() as round 2 left it (restated here so that later fusions do not move it)."""
+    metrics = set(metrics)
+    total = 0.0
+    for b in buckets:
+        P, R, S = b.n_pairs, b.n_refs, b.n_pairs + b.n_refs
+        unit = {"P": P, "R": R, "S": S}
+        for name, (pyr, rows) in R02_MODEL.items():
+            if ("ssimulacra2" if pyr == "ssim2" else "dssim") not in metrics:
+                continue
+            if pyr == "ssim2" and min(b.width, b.height) < 8:
+                continue
+            lv = ssim2_levels(b.width, b.height) if pyr == "ssim2" else dssim_levels(b.width, b.height)
+            for l, (w, h) in enumerate(lv):
+                nn = lv[l + 1][0] * lv[l + 1][1] if l + 1 < len(lv) else 0
+                for u, b0, b1, bn in rows:
+                    total += unit[u] * ((b0 if l == 0 else b1) * w * h + bn * nn)
+        if "butteraugli" in metrics and min(b.width, b.height) >= 8:
+            lv = butteraugli_levels(b.width, b.height)
+            for l, (w, h) in enumerate(lv):
+                n = w * h
+                total += S * (n * 15 if l == 0 else 3 * b.px + 12 * n)            # front end
+                total += S * n * (24 + 48 + 32 + 28 + 8) + R * n * 12               # blur stages, mask values
+                io = 4 * P if l == 1 else (P if len(lv) == 2 else 0)
+                total += n * (44 * P + 52 * R) + n * io                            # Malta + L2 + combine
+        if "psnr" in metrics:
+            total += 3.0 * b.px * (P + R)
+        if xyb_roundtrip:
+            total += 6.0 * b.px * R
+    return total
+
+
 METRIC_OF_PREFIX = (("ssim2_", "ssimulacra2"), ("dssim_", "dssim"), ("ba_", "butteraugli"), ("psnr", "psnr"), ("xyb_", "xyb_roundtrip"))
 
 

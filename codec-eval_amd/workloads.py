@@ -118,6 +118,21 @@ class Grid:
         return len(self.pairs) * self.width * self.height / 1e6
 
 
+def _one_reference(job):
+    """(reference, [distorted images of its units, unit-major then quality]) of one source image: the work a pool worker does."""
+    w, h, seed, kind, s420_list, qualities = job
+    ref = make_reference(w, h, seed, kind)
+    return ref, [distort(ref, q, s420) for s420 in s420_list for q in qualities]
+
+
+_POOL_WORKERS = 0  # set_generation_workers(): > 1 = build grids with a fork pool (call before anything initialises HIP)
+
+
+def set_generation_workers(n: int):
+    global _POOL_WORKERS
+    _POOL_WORKERS = max(0, int(n))
+
+
 def _grid(name, w, h, n_refs, seed0, qualities, variants=((False,),), kinds=None, only=None, units=None) -> Grid:
     """only: global reference indices to generate (a rank's shard; default all).  units: (reference, variant) pairs
     to generate instead (partition by (image, codec-config)) - a reference listed with several
@@ -125,15 +140,31 @@ def _grid(name, w, h, n_refs, seed0, qualities, variants=((False,),), kinds=None
     same bytes as the same cells of the whole grid."""
     if units is None:
         units = [(i, v) for i in (range(n_refs) if only is None else only) for v in range(len(variants))]
-    refs, pairs, ref_ids, pair_ids, local = [], [], [], [], {}
+    order, by_ref = [], {}
     for i, v in units:
-        if i not in local:
-            local[i] = len(refs)
-            refs.append(make_reference(w, h, seed0 + i, (kinds or {}).get(i, "natural")))
-            ref_ids.append(i)
-        (s420,) = variants[v]
-        for qi, q in enumerate(qualities):
-            pairs.append((local[i], distort(refs[local[i]], q, s420)))
+        if i not in by_ref:
+            by_ref[i] = []
+            order.append(i)
+        by_ref[i].append(v)
+    jobs = [(w, h, seed0 + i, (kinds or {}).get(i, "natural"), [variants[v][0] for v in by_ref[i]], tuple(qualities)) for i in order]
+    if _POOL_WORKERS > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(min(_POOL_WORKERS, len(jobs))) as pool:
+            made = pool.map(_one_reference, jobs, chunksize=1)
+    else:
+        made = [_one_reference(j) for j in jobs]
+    refs, pairs, ref_ids, pair_ids, local = [], [], [], [], {}
+    tests_of = {}
+    for i, (ref, tests) in zip(order, made):
+        local[i] = len(refs)
+        refs.append(ref)
+        ref_ids.append(i)
+        for k, v in enumerate(by_ref[i]):
+            tests_of[(i, v)] = tests[k * len(qualities):(k + 1) * len(qualities)]
+    for i, v in units:  # the caller's unit order, as before
+        for qi in range(len(qualities)):
+            pairs.append((local[i], tests_of[(i, v)][qi]))
             pair_ids.append((i, v, qi))
     return Grid(name, w, h, refs, pairs, ref_ids, pair_ids)
 

@@ -598,24 +598,31 @@ static void diffmap_psycho(const psycho *pi0, const psycho *pi1, img *diffmap)
         ac[c] = img_new(w, h);
         dc[c] = img_new(w, h);
     }
+    const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f,
+                           29.2353797994f, 0.844626970982f, 0.703646627719f};
+    /* CEO_V_BA_L2_EARLY: the in-place L2 accumulations of channels X and Y run between the Malta bands (the order the
+     * device's fused kernel meets the bands in); default: after all Malta bands, as the lineage calls them */
+    const int early = ceo_variant[CEO_V_BA_L2_EARLY];
     const double wUhfMalta = 1.10039032555, norm1Uhf = 71.7800275169;
     malta_diff_map(&pi0->uhf[1], &pi1->uhf[1], wUhfMalta * hf_asymmetry, wUhfMalta / hf_asymmetry, norm1Uhf, 0, &ac[1]);
     const double wUhfMaltaX = 173.5, norm1UhfX = 5.0;
     malta_diff_map(&pi0->uhf[0], &pi1->uhf[0], wUhfMaltaX * hf_asymmetry, wUhfMaltaX / hf_asymmetry, norm1UhfX, 0, &ac[0]);
+    if (early)
+        for (int c = 0; c < 2; c++) l2_diff_asymmetric(&pi0->hf[c], &pi1->hf[c], wmul[c] * hf_asymmetry, wmul[c] / hf_asymmetry, &ac[c]);
     const double wHfMalta = 18.7237414387, norm1Hf = 4498534.45232;
     malta_diff_map(&pi0->hf[1], &pi1->hf[1], wHfMalta * sqrt(hf_asymmetry), wHfMalta / sqrt(hf_asymmetry), norm1Hf, 1, &ac[1]);
     const double wHfMaltaX = 6923.99476109, norm1HfX = 8051.15833247;
     malta_diff_map(&pi0->hf[0], &pi1->hf[0], wHfMaltaX * sqrt(hf_asymmetry), wHfMaltaX / sqrt(hf_asymmetry), norm1HfX, 1, &ac[0]);
+    if (early)
+        for (int c = 0; c < 2; c++) l2_diff(&pi0->mf[c], &pi1->mf[c], wmul[3 + c], &ac[c], 0);
     const double wMfMalta = 37.0819870399, norm1Mf = 130262059.556;
     malta_diff_map(&pi0->mf[1], &pi1->mf[1], wMfMalta, wMfMalta, norm1Mf, 1, &ac[1]);
     const double wMfMaltaX = 8246.75321353, norm1MfX = 1009002.70582;
     malta_diff_map(&pi0->mf[0], &pi1->mf[0], wMfMaltaX, wMfMaltaX, norm1MfX, 1, &ac[0]);
 
-    const float wmul[9] = {400.0f, 1.50815703118f, 0.0f, 2150.0f, 10.6195433239f, 16.2176043152f,
-                           29.2353797994f, 0.844626970982f, 0.703646627719f};
     for (int c = 0; c < 3; c++) {
-        if (c < 2) l2_diff_asymmetric(&pi0->hf[c], &pi1->hf[c], wmul[c] * hf_asymmetry, wmul[c] / hf_asymmetry, &ac[c]);
-        l2_diff(&pi0->mf[c], &pi1->mf[c], wmul[3 + c], &ac[c], 0);
+        if (c < 2 && !early) l2_diff_asymmetric(&pi0->hf[c], &pi1->hf[c], wmul[c] * hf_asymmetry, wmul[c] / hf_asymmetry, &ac[c]);
+        if (c == 2 || !early) l2_diff(&pi0->mf[c], &pi1->mf[c], wmul[3 + c], &ac[c], 0);
         l2_diff(&pi0->lf[c], &pi1->lf[c], wmul[6 + c], &dc[c], 1);
     }
     img mask = img_new(w, h);

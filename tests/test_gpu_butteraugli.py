@@ -91,3 +91,40 @@ def test_malta_shared_reciprocal_division_is_exact(gpu_ctx):
     must equal operator/ bit for bit."""
     for seed in (1, 0x1234567):
         assert gpu_ctx.debug_div_sweep(seed, 1 << 31) == 0
+
+
+def test_device_is_the_oracle_with_two_named_switches_bit_for_bit(gpu_ctx, oracle, ce, workloads):
+    """Round 3 trades two operation-order choices for speed in the Malta kernel, each with a switch in the oracle and a row in
+    the sensitivity ledger (tests/golden/sensitivity.json: both < 1e-6 of the score): the asymmetry term of the Malta
+    pre-scaling in f32 ("ba_malta_f32") and the HF / MF L2 terms accumulated between the Malta bands ("ba_l2_early").  With
+    those two switches ON the oracle is the device's arithmetic exactly: the scores (the maximum of the diffmap) must be EQUAL
+    and the 3-norms agree to f64 round-off (the device adds the same f64 terms tile by tile); against the default oracle both
+    stay within 1e-6."""
+    cases = []
+    for (w, h, seed, q) in ((64, 33, 1, 40), (129, 65, 2, 75), (200, 136, 3, 90), (768, 512, 4, 85)):
+        ref = workloads.make_reference(w, h, 900 + seed)
+        cases.append((w, h, ref, workloads.distort(ref, q, seed % 2 == 0)))
+    flat = workloads.make_reference(96, 96, 5, "flat")
+    noisy = np.clip(flat.astype(np.int16) + np.random.default_rng(5).integers(-3, 4, flat.shape), 0, 255).astype(np.uint8)
+    cases.append((96, 96, flat, noisy))
+    got = []
+    for w, h, ref, t in cases:
+        b = ce.Batch(gpu_ctx, w, h, 1, 1)
+        b.set_reference(0, ref)
+        b.set_test(0, 0, t)
+        s = b.run(1, ce.MetricConfig(butteraugli=True))
+        got.append((s[0].butteraugli, float(b.butteraugli_pnorm3(1)[0])))
+        b.close()
+    base = [oracle.butteraugli(ref, t, w, h) for w, h, ref, t in cases]
+    assert oracle.variants_all_default()
+    oracle.set_variant("ba_malta_f32", 1)
+    oracle.set_variant("ba_l2_early", 1)
+    try:
+        same = [oracle.butteraugli(ref, t, w, h) for w, h, ref, t in cases]
+    finally:
+        oracle.set_variant("ba_malta_f32", 0)
+        oracle.set_variant("ba_l2_early", 0)
+    assert oracle.variants_all_default()
+    for g, s, d in zip(got, same, base):
+        assert g[0] == s[0] and abs(g[1] - s[1]) <= 1e-13 * abs(s[1]), (g, s)
+        assert abs(g[0] - d[0]) <= 1e-6 * max(abs(d[0]), 1e-3) and abs(g[1] - d[1]) <= 1e-6 * max(abs(d[1]), 1e-3), (g, d)
