@@ -75,6 +75,22 @@ __device__ __forceinline__ uint32_t mirror(int x, int n)
 // outputs are scaled by 1 / (sum of their valid weights).
 constexpr int BW_OUT = 8;
 
+// A tap of the long blurs: sum + v * k with the lineage's two roundings (bit-identical planes).  -DCE_BA_BLUR_FMA=1 builds
+// the taps as ONE fused multiply-add - the oracle's switch "ba_blur_fma" bit for bit - for A/B runs: measured in round 3
+// at +3 % of the headline (the five blur kernels 1.86 -> 1.70 ms per Kodak step) for a score that moves by up to 6e-5
+// relative on small shapes (profiles/r03_experiments.md section 3): too close to the 1e-4 contract, not adopted.
+#ifndef CE_BA_BLUR_FMA
+#define CE_BA_BLUR_FMA 0
+#endif
+__device__ __forceinline__ float blur_tap(float sum, float v, float k)
+{
+#if CE_BA_BLUR_FMA
+    return __builtin_fmaf(v, k, sum);
+#else
+    return sum + v * k;
+#endif
+}
+
 template <int LEN>
 __device__ __forceinline__ float border_scale(const blur_kernel &bk, int pos, int n, float inv_wsum)
 {
@@ -174,8 +190,12 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
             for (int j = 0; j < LEN; j++) {
                 const int idx = 2 * op + j;
                 const ba_f2 src = (idx & 1) ? po[idx >> 1] : pe[idx >> 1];
+#if CE_BA_BLUR_FMA
+                sum = __builtin_elementwise_fma(src, ba_f2{bk.k[j], bk.k[j]}, sum);
+#else
                 const ba_f2 prod = src * ba_f2{bk.k[j], bk.k[j]};
                 sum = sum + prod;
+#endif
             }
             res[2 * op] = sum.x * border_scale<LEN>(bk, gx0 + 2 * op, (int)g.w, inv_wsum);
             res[2 * op + 1] = sum.y * border_scale<LEN>(bk, gx0 + 2 * op + 1, (int)g.w, inv_wsum);
@@ -505,7 +525,7 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                 for (int k = 0; k < 4; k++) {
                     float sum = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < LEN; j++) sum += wnd[S0 + k + j] * bk.k[j];
+                    for (int j = 0; j < LEN; j++) sum = blur_tap(sum, wnd[S0 + k + j], bk.k[j]);
                     out[k] = sum * scale_x[k];  // scale 0 right of the image: the column pass sees zeros there
                 }
                 *reinterpret_cast<float4 *>(tile + r * TW + rc4) = make_float4(out[0], out[1], out[2], out[3]);
@@ -529,7 +549,7 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
                 for (int o = 0; o < BW_OUT; o++) {
                     float sum = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < LEN; j++) sum += v[o + j] * bk.k[j];
+                    for (int j = 0; j < LEN; j++) sum = blur_tap(sum, v[o + j], bk.k[j]);
                     res[q][part][o] = sum * border_scale<LEN>(bk, gy0 + o, (int)g.h, inv_wsum);
                 }
             }

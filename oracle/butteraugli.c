@@ -55,6 +55,8 @@ static int compute_kernel(float sigma, float *kernel /* >= 2*diff+1 */)
     return 2 * diff + 1;
 }
 
+extern int ceo_variant[CEO_V_COUNT]; /* sensitivity switches, all 0 by default (ce_oracle.h) */
+
 static size_t mirror(ptrdiff_t x, ptrdiff_t n)
 {
     while (x < 0 || x >= n) {
@@ -75,18 +77,25 @@ static void conv_line_renorm(const float *in, ptrdiff_t n, ptrdiff_t stride, con
     float wsum = 0.0f;
     for (int j = 0; j < len; j++) wsum += kernel[j];
     const float scale_no_border = 1.0f / wsum;
+    const int fused = ceo_variant[CEO_V_BA_BLUR_FMA]; /* same taps, same order, one rounding per tap instead of two */
     for (ptrdiff_t x = 0; x < n; x++) {
         ptrdiff_t lo = x - off < 0 ? 0 : x - off;
         ptrdiff_t hi = x + off > n - 1 ? n - 1 : x + off;
         float sum = 0.0f;
         if (lo == x - off && hi == x + off) {
-            for (ptrdiff_t j = lo; j <= hi; j++) sum += in[j * stride] * kernel[j - x + off];
+            if (fused)
+                for (ptrdiff_t j = lo; j <= hi; j++) sum = fmaf(in[j * stride], kernel[j - x + off], sum);
+            else
+                for (ptrdiff_t j = lo; j <= hi; j++) sum += in[j * stride] * kernel[j - x + off];
             out[x * ostride] = sum * scale_no_border;
         } else {
             float weight = 0.0f;
             for (ptrdiff_t j = lo; j <= hi; j++) weight += kernel[j - x + off];
             const float scale = 1.0f / weight;
-            for (ptrdiff_t j = lo; j <= hi; j++) sum += in[j * stride] * kernel[j - x + off];
+            if (fused)
+                for (ptrdiff_t j = lo; j <= hi; j++) sum = fmaf(in[j * stride], kernel[j - x + off], sum);
+            else
+                for (ptrdiff_t j = lo; j <= hi; j++) sum += in[j * stride] * kernel[j - x + off];
             out[x * ostride] = sum * scale;
         }
     }

@@ -59,7 +59,8 @@ enum ceo_variant_key {
     CEO_V_SSIM2_F32_POOL = 7,      /* per-pixel map terms summed in f32 per row before the f64 pool */
     CEO_V_BA_L2_EARLY = 8,         /* the HF / MF L2 terms join block_diff_ac between the Malta bands (uhf, L2asym(hf), hf, L2(mf), mf)
                                       instead of after all three: the same in-place accumulations in another order */
-    CEO_V_COUNT = 9
+    CEO_V_BA_BLUR_FMA = 9,         /* the taps of the long separable blurs (sigma 1.56 .. 7.16) accumulate with fused multiply-add */
+    CEO_V_COUNT = 10
 };
 void ceo_set_variant(int key, int value);
 int ceo_get_variant(int key);

@@ -109,7 +109,7 @@ def srgb_u8_to_linear(v: int) -> float:
 
 
 VARIANTS = {"ssim2_srgb_f32_powf": 0, "ssim2_host_cbrtf": 1, "ssim2_iir_no_fma": 2, "dssim_lab_no_fma": 3,
-            "dssim_f32_final": 4, "ba_malta_f32": 5, "ba_libm_log2": 6, "ssim2_f32_pool": 7, "ba_l2_early": 8}
+            "dssim_f32_final": 4, "ba_malta_f32": 5, "ba_libm_log2": 6, "ssim2_f32_pool": 7, "ba_l2_early": 8, "ba_blur_fma": 9}
 
 
 def set_variant(name: str, value: int):
