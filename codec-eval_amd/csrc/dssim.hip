@@ -40,34 +40,6 @@ __global__ __launch_bounds__(TPB) void k_rgb8_to_rgba_f32(const uint8_t *__restr
         out[i] = make_float4(s_lut[rgb[3 * i]], s_lut[rgb[3 * i + 1]], s_lut[rgb[3 * i + 2]], 1.0f);
 }
 
-// ---- linear RGB -> normalised (L, a, b) ------------------------------------------------------------
-__device__ __forceinline__ float cbrt_poly(float x)
-{
-    // x in (216/24389, ~1], y in [0.2, 1.1]: numerators and denominators in (0.005, 3.5) - the two IEEE quotients take the
-    // expansion without range scaling (ce_internal.h: 8 instructions instead of 11, bit for bit; this kernel is VALU-bound)
-    float y = (-0.5f * x + 1.51f) * x + 0.2f;
-    float y3 = y * y * y;
-    y = ce_div_noscale(y * (y3 + 2.0f * x), 2.0f * y3 + x);
-    y3 = y * y * y;
-    y = ce_div_noscale(y * (y3 + 2.0f * x), 2.0f * y3 + x);
-    return y;
-}
-
-__device__ __forceinline__ void rgb_to_lab(float r, float g, float b, float &L, float &A, float &B)
-{
-    const float D65X = 0.9505f, D65Y = 1.0f, D65Z = 1.089f;
-    const float EPS = 216.0f / 24389.0f, K = 24389.0f / (27.0f * 116.0f);
-    const float fx = __builtin_fmaf(b, 0.1805f / D65X, __builtin_fmaf(g, 0.3576f / D65X, r * (0.4124f / D65X)));
-    const float fy = __builtin_fmaf(b, 0.0722f / D65Y, __builtin_fmaf(g, 0.7152f / D65Y, r * (0.2126f / D65Y)));
-    const float fz = __builtin_fmaf(b, 0.9505f / D65Z, __builtin_fmaf(g, 0.1192f / D65Z, r * (0.0193f / D65Z)));
-    const float X = fx > EPS ? cbrt_poly(fx) - 16.0f / 116.0f : K * fx;
-    const float Y = fy > EPS ? cbrt_poly(fy) - 16.0f / 116.0f : K * fy;
-    const float Z = fz > EPS ? cbrt_poly(fz) - 16.0f / 116.0f : K * fz;
-    L = Y * 1.05f;
-    A = __builtin_fmaf(500.0f / 220.0f, X - Y, 86.2f / 220.0f);
-    B = __builtin_fmaf(200.0f / 220.0f, Y - Z, 107.9f / 220.0f);
-}
-
 // One 3x3 pass with edge replication, evaluated on an LDS region of width RW whose local (0,0) is global
 // (gx0, gy0).  The centre (lx, ly) must be inside the image; neighbours are clamped in GLOBAL coordinates,
 // which is exactly "replicate the edge of that pass's input".  SQ squares every tap (blur of the squared
@@ -623,6 +595,10 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         const char *e = std::getenv("CE_DSSIM_COMPARE");
         return e && std::string(e) == "tile";
     }();
+    static const bool tile_create = [] {  // CE_DSSIM_CREATE=tile: round 2's LDS-tile create_image kernel (A/B knob)
+        const char *e = std::getenv("CE_DSSIM_CREATE");
+        return e && std::string(e) == "tile";
+    }();
     ds_geom g{};
     for (int l = 0; l < b->ds_levels; l++) {
         const auto &d = b->ds[l];
@@ -631,7 +607,9 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         const lvl_geom lg{d.w, d.h, d.pitch, d.plane}, ng{nd.w, nd.h, nd.pitch, nd.plane};
         const dim3 tiles((d.w + DT - 1) / DT, (d.h + DT - 1) / DT, 1);
         // create_image for every used slot (references once per reference)
-        if (l == 0)
+        if (!tile_create) {
+            if ((rc = ce_dssim_create_stream(b, l, d_refs, n_refs_used, n_pairs, z0)) != CE_OK) return rc;
+        } else if (l == 0)
             CE_LAUNCH(ctx, "dssim_create_u8", k_dssim_create<true>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
                       ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_rimg[l], b->ds_rmu[l],
                       b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);

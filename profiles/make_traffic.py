@@ -33,7 +33,7 @@ SHORT = [
     (r"k_ssim2_hblur_lds<-1>", "ssim2_hblur_L1-5"), (r"k_ssim2_vblur_dma<-1>", "ssim2_vblur_ssim_L1-5"),
     (r"k_ssim2_hblur_lds<0>", "ssim2_hblur_L0"), (r"k_ssim2_vblur_dma<0>", "ssim2_vblur_ssim_L0"),
     (r"k_ssim2_prep<true>", "ssim2_prep_u8"), (r"k_ssim2_prep<false>", "ssim2_prep"), (r"k_ssim2_finalize", "ssim2_finalize"),
-    (r"k_dssim_create<true>", "dssim_create_u8"), (r"k_dssim_create<false>", "dssim_create"), (r"k_dssim_compare", "dssim_compare"),
+    (r"k_dssim_create_stream<true", "dssim_create_u8"), (r"k_dssim_create_stream<false", "dssim_create"), (r"k_dssim_create<true>", "dssim_create_u8"), (r"k_dssim_create<false>", "dssim_create"), (r"k_dssim_compare", "dssim_compare"),
     (r"k_dssim_avg", "dssim_avg"), (r"k_dssim_absdev", "dssim_absdev"), (r"k_dssim_finalize_pairs", "dssim_finalize"),
     (r"k_ba_front<false>", "ba_front_u8"), (r"k_ba_front<true>", "ba_front_half"), (r"k_ba_subsample2x_u8", "ba_subsample2x"),
     (r"k_ba_blur_h<(\d+)>", "ba_blur_h{}"), (r"k_ba_blur_v<(\d+)>", "ba_blur_v{}"),
