@@ -1255,7 +1255,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     ce_ctx *ctx = b->ctx;
     int rc = ba_prepare(b);
     if (rc != CE_OK) return rc;
-    const uint32_t n_slots = n_refs_used + n_pairs, mr = b->max_refs, P = b->max_pairs;
+    const uint32_t n_slots = n_refs_used + n_pairs, mr = b->max_refs;
     // reference handle (ce_ref_*): the references' PsychoImage (both resolutions) of an earlier launch with the same
     // intensity target is still in ba_psy, so only the distorted slots go through the per-image chain
     const bool cached = b->keep_ref_pyramid && b->ba_ref_src == d_refs && b->ba_ref_count >= n_refs_used && b->ba_ref_intensity == intensity_target;

@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <cmath>
 #include <cstdlib>
@@ -216,11 +219,69 @@ int ce_ctx_create_on_stream(int device, void *hip_stream, ce_ctx **out)
 
 int ce_ctx_create(int device, ce_ctx **out) { return ce_ctx_create_on_stream(device, nullptr, out); }
 
+// Parked helper threads of a context.  Round 2 spawned a std::thread per chain and call: creating a thread and making its
+// first HIP call cost ~50-100 us, more than the 0.2 ms of launches it was meant to overlap (a single 768x512 pair traced in
+// round 3: 96 us between the upload and the first kernel, the third chain starting 190 us after the first).  A helper sets
+// its device once and sleeps on a condition variable between jobs.
+struct ce_fork_helpers {
+    struct worker {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        std::function<void()> job;
+        bool has_job = false, done = true, stop = false;
+    } w[2];
+    explicit ce_fork_helpers(int device)
+    {
+        for (auto &x : w)
+            x.th = std::thread([&x, device] {
+                (void)hipSetDevice(device);
+                std::unique_lock<std::mutex> lk(x.m);
+                for (;;) {
+                    x.cv.wait(lk, [&] { return x.has_job || x.stop; });
+                    if (x.stop) return;
+                    x.has_job = false;
+                    lk.unlock();
+                    x.job();
+                    lk.lock();
+                    x.done = true;
+                    x.cv.notify_all();
+                }
+            });
+    }
+    void submit(int i, std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> lk(w[i].m);
+        w[i].job = std::move(f);
+        w[i].has_job = true;
+        w[i].done = false;
+        w[i].cv.notify_all();
+    }
+    void wait(int i)
+    {
+        std::unique_lock<std::mutex> lk(w[i].m);
+        w[i].cv.wait(lk, [&] { return w[i].done; });
+    }
+    ~ce_fork_helpers()
+    {
+        for (auto &x : w) {
+            {
+                std::lock_guard<std::mutex> lk(x.m);
+                x.stop = true;
+                x.cv.notify_all();
+            }
+            if (x.th.joinable()) x.th.join();
+        }
+    }
+};
+
 void ce_ctx_destroy(ce_ctx *ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    delete ctx->helpers;
+    ctx->helpers = nullptr;
     prof_drain(ctx);
     for (auto &kv : ctx->shape_pool) ce_batch_destroy(kv.second);
     ctx->shape_pool.clear();
@@ -354,14 +415,19 @@ static void invalidate_reference_state(ce_batch *b)
     b->refs_rt_valid = false;
 }
 
-static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src)
+static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src, bool allow_inline = true)
 {
     ce_ctx *ctx = b->ctx;
     // pageable source -> pinned staging ring -> device on the batch's upload stream.  The caller's buffer is
     // consumed before this returns; the DMA of this slot overlaps the host copy into the next one and the
     // kernels of other batches.  A launched-but-uncollected run of THIS batch still reads the slabs: wait for it.
     CE_HIP(ctx, hipSetDevice(ctx->device));  // the calling thread's current device may be another one (multi-device hosts)
-    if (b->run_pending) {
+    // A small batch (the one-pair-per-call regime of a reference handle) uploads on the context's own stream: its launch
+    // follows at once, and a cross-stream event between the copy and the first kernel costs ~25 us of its ~0.5 ms
+    // (not for an image that a format conversion or a colour table follows on the upload stream: allow_inline = false)
+    const bool inline_copy = allow_inline && (double)b->max_pairs * b->w * b->h <= 4e6;
+    hipStream_t us = inline_copy ? ctx->stream : b->up_stream;
+    if (b->run_pending && !inline_copy) {
         CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
         b->run_pending = false;  // ordered from here on
     }
@@ -369,10 +435,10 @@ static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src)
     b->next_stage = (k + 1) % ce_batch::kStages;
     if (b->stage_busy[k]) CE_HIP(ctx, hipEventSynchronize(b->ev_stage[k]));
     std::memcpy(b->h_stage[k], src, b->img_bytes);
-    CE_HIP(ctx, hipMemcpyAsync(dst, b->h_stage[k], b->img_bytes, hipMemcpyHostToDevice, b->up_stream));
-    CE_HIP(ctx, hipEventRecord(b->ev_stage[k], b->up_stream));
+    CE_HIP(ctx, hipMemcpyAsync(dst, b->h_stage[k], b->img_bytes, hipMemcpyHostToDevice, us));
+    CE_HIP(ctx, hipEventRecord(b->ev_stage[k], us));
     b->stage_busy[k] = true;
-    b->uploads_pending = true;
+    if (!inline_copy) b->uploads_pending = true;
     return CE_OK;
 }
 
@@ -434,7 +500,7 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
                                                  (size_t)std::max(1u, std::thread::hardware_concurrency())});
     if (n_threads <= 1 || b->img_bytes < (64u << 10)) {
         for (const auto &j : jobs) {
-            int rc = upload(b, j.dst, j.src);
+            int rc = upload(b, j.dst, j.src, false);
             if (rc != CE_OK) return rc;
         }
         return CE_OK;
@@ -506,7 +572,7 @@ static int upload_fmt(ce_batch *b, uint8_t *dst, const void *pixels, size_t len,
     if (len != n_px * bpp)
         return fail(ctx, CE_ERR_BAD_LENGTH, "Invalid image size: expected " + std::to_string(n_px * bpp) + " bytes, got " +
                                                 std::to_string(len));
-    if (format == CE_PIXEL_RGB8) return upload(b, dst, static_cast<const uint8_t *>(pixels));
+    if (format == CE_PIXEL_RGB8) return upload(b, dst, static_cast<const uint8_t *>(pixels), false);
     CE_HIP(ctx, hipSetDevice(ctx->device));  // the staging allocations and the ingest launch below go to the context's device
     if (!b->h_wide) {
         CE_HIP(ctx, hipHostMalloc(&b->h_wide, n_px * 8, hipHostMallocDefault));
@@ -688,11 +754,8 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         }
         d_refs = b->d_refs_rt;
     }
-    if (metric_mask & CE_METRIC_PSNR) {
-        int rc = ce_launch_psnr(b, d_refs, n_pairs);
-        if (rc != CE_OK) return rc;
-    }
-    // The three perceptual metrics are independent chains over their own buffers.
+    // The three perceptual metrics are independent chains over their own buffers (PSNR - two short launches on the
+    // context's stream - is enqueued after them, so that forked chains do not wait behind it).
     const bool run_ssim2 = (metric_mask & CE_METRIC_SSIMULACRA2) && b->w >= 8 && b->h >= 8;
     const bool run_dssim = (metric_mask & CE_METRIC_DSSIM) != 0;
     const bool run_ba = (metric_mask & CE_METRIC_BUTTERAUGLI) && b->w >= 8 && b->h >= 8;
@@ -785,24 +848,24 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
             ce_tls_stream = nullptr;
             if (rcs[k] == CE_OK && hipEventRecord(b->ev_join[k], b->metric_stream[k]) != hipSuccess) rcs[k] = CE_ERR_BACKEND;
         };
-        std::vector<std::thread> helpers;
+        if (!ctx->helpers) {
+            try {
+                ctx->helpers = new ce_fork_helpers(ctx->device);
+            } catch (...) {  // no threads to be had: every chain is enqueued here (nothing may be thrown across the C ABI)
+                ctx->helpers = nullptr;
+            }
+        }
+        int used = 0;
         for (int i = 0; i < 3; i++) {
             const int k = fork_order[i];
             if (!runs[k] || k == last) continue;
-            try {
-                helpers.emplace_back([&, k] {
-                    if (hipSetDevice(ctx->device) != hipSuccess) {
-                        rcs[k] = CE_ERR_BACKEND;
-                        return;
-                    }
-                    body(k);
-                });
-            } catch (...) {  // no thread to be had: enqueue this chain here (nothing may be thrown across the C ABI)
+            if (ctx->helpers && used < 2)
+                ctx->helpers->submit(used++, [&body, k] { body(k); });
+            else
                 body(k);
-            }
         }
         body(last);  // the caller's thread takes the chain that is enqueued last in the single-threaded order
-        for (auto &t : helpers) t.join();
+        for (int i = 0; i < used; i++) ctx->helpers->wait(i);
         for (int k = 0; k < 3; k++) {
             if (!runs[k]) continue;
             if (rcs[k] != CE_OK) return rcs[k];
@@ -826,6 +889,10 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
             CE_HIP(ctx, hipEventRecord(b->ev_join[k], b->metric_stream[k]));
             joined |= 1u << k;  // the context's stream waits for it after every chain has been launched
         }
+    }
+    if (metric_mask & CE_METRIC_PSNR) {
+        int rc = ce_launch_psnr(b, d_refs, n_pairs);
+        if (rc != CE_OK) return rc;
     }
     for (int k = 0; k < 3; k++)
         if (joined & (1u << k)) CE_HIP(ctx, hipStreamWaitEvent(base, b->ev_join[k], 0));
@@ -916,8 +983,8 @@ size_t ce_estimate_batch_bytes(uint32_t w, uint32_t h, uint32_t n_refs, uint32_t
         bytes += px * (20.0 * slots + 80.0 * pairs);
         allocations += 24;
     }
-    if (metric_mask & CE_METRIC_DSSIM) {  // linear ping-pong 6 per slot; img 12 + SSIM map 4 per pair; the references' per-level img / mu / sq 48
-        bytes += px * (6.0 * slots + 48.0 * n_refs + 16.0 * pairs);
+    if (metric_mask & CE_METRIC_DSSIM) {  // linear ping-pong 6 per slot; img 12 + the SSIM maps of all levels 5.4 per pair; the references' per-level img / mu / sq 48
+        bytes += px * (6.0 * slots + 48.0 * n_refs + 17.4 * pairs);
         allocations += 24;
     }
     if (metric_mask & CE_METRIC_BUTTERAUGLI) {  // PsychoImage 50, mask input 5, three 3-plane scratch sets 36 per slot; mask values 10 per reference; half-resolution diffmap 1 per pair

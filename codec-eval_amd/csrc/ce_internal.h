@@ -75,6 +75,10 @@ struct ce_ctx {
     // bucket through them in chunks so that the upload of one chunk overlaps the kernels of the previous one)
     static constexpr uint32_t kPoolRing = 3;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ce_batch *> shape_pool;
+
+    // two parked host threads that enqueue the other metric chains of a forked batch (ce_api.cpp: ce_fork_helpers); made on
+    // the first forked launch, joined by ce_ctx_destroy
+    struct ce_fork_helpers *helpers = nullptr;
 };
 
 // XCD-aware 1-D launch order for per-pair tile kernels (ce_build_xcd_list, ce_api.cpp): entry = (tile, pair)

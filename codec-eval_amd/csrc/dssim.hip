@@ -428,14 +428,21 @@ __global__ __launch_bounds__(TPB, 3) void k_dssim_compare(const float *__restric
     if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + wi.x] = t;
 }
 
-// ---- avg = max(mean, 0)^(0.5^level): one block per pair reduces the SSIM partial sums in a fixed order ----
-__global__ __launch_bounds__(TPB) void k_dssim_avg(const double *__restrict__ part, double *__restrict__ avg_out, uint32_t w,
-                                                   uint32_t h, uint32_t level, uint32_t n_levels, uint32_t n_blocks,
-                                                   uint32_t used_blocks)
+// ---- the tail of every level in two launches (round 3: one avg + one absdev launch per LEVEL were ten of DSSIM's 21 dependent
+// launches, each ~4.5 us on the critical path of a single-pair call) ------------------------------------------------------
+struct ds_tail {
+    uint32_t w[CE_DSSIM_SCALES], h[CE_DSSIM_SCALES], pitch[CE_DSSIM_SCALES], n_part[CE_DSSIM_SCALES], gx[CE_DSSIM_SCALES];
+    size_t plane[CE_DSSIM_SCALES], map_off[CE_DSSIM_SCALES];  // the level's SSIM maps start at map + map_off[l], one plane per pair
+};
+
+// avg = max(mean, 0)^(0.5^level): one block per (pair, level) reduces the compare kernel's partial sums in a fixed order
+__global__ __launch_bounds__(TPB) void k_dssim_avg(const double *__restrict__ part, double *__restrict__ avg_out, ds_tail t, uint32_t n_levels,
+                                                   uint32_t n_blocks)
 {
     __shared__ double s_red[TPB];
-    const uint32_t p = blockIdx.x;
+    const uint32_t p = blockIdx.x, level = blockIdx.y;
     const double *pp = part + ((size_t)p * n_levels + level) * 2 * n_blocks;
+    const uint32_t used_blocks = t.n_part[level];
     double v = 0.0;
     for (uint32_t k = threadIdx.x; k < used_blocks; k += TPB) v += pp[k];
     s_red[threadIdx.x] = v;
@@ -445,32 +452,34 @@ __global__ __launch_bounds__(TPB) void k_dssim_avg(const double *__restrict__ pa
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        double avg = s_red[0] / (double)((size_t)w * h);
+        double avg = s_red[0] / (double)((size_t)t.w[level] * t.h[level]);
         if (!(avg > 0.0)) avg = 0.0;
         avg_out[(size_t)p * n_levels + level] = pow(avg, pow(0.5, (double)level));
     }
 }
 
-// ---- mean absolute deviation of the SSIM map from avg ------------------------------------------------------
+// mean absolute deviation of the SSIM map from avg; grid = level 0's blocks x (pairs x levels), a level's surplus blocks leave
 constexpr int AD_ROWS = 32;  // rows per block
 __global__ __launch_bounds__(TPB) void k_dssim_absdev(const float *__restrict__ map, const double *__restrict__ avg_in,
-                                                      double *__restrict__ part, uint32_t w, uint32_t h, uint32_t pitch,
-                                                      size_t plane, uint32_t level, uint32_t n_levels, uint32_t n_blocks)
+                                                      double *__restrict__ part, ds_tail t, uint32_t n_levels, uint32_t n_blocks)
 {
     __shared__ double s_red[TPB / 64];
-    const uint32_t p = blockIdx.z;
+    const uint32_t p = blockIdx.z / n_levels, level = blockIdx.z % n_levels;
+    const uint32_t w = t.w[level], h = t.h[level], pitch = t.pitch[level];
+    if (blockIdx.x >= t.gx[level] || blockIdx.y * AD_ROWS >= h) return;  // block-uniform
     double *pp = part + ((size_t)p * n_levels + level) * 2 * n_blocks;
     const double avg = avg_in[(size_t)p * n_levels + level];
+    const float *m = map + t.map_off[level] + (size_t)p * t.plane[level];
     // block = 64 columns x 32 rows, a thread walks 8 rows (stride 4): one block reduction per 2048 pixels
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
     double val = 0.0;
 #pragma unroll
     for (int k = 0; k < AD_ROWS / 4; k++) {
         const uint32_t y = blockIdx.y * AD_ROWS + 4 * k + (threadIdx.x >> 6);
-        if (x < w && y < h) val += fabs(avg - (double)map[(size_t)p * plane + (size_t)y * pitch + x]);
+        if (x < w && y < h) val += fabs(avg - (double)m[(size_t)y * pitch + x]);
     }
-    const double t = block_sum(val, s_red);
-    if (threadIdx.x == 0) pp[n_blocks + blockIdx.y * gridDim.x + blockIdx.x] = t;
+    const double s = block_sum(val, s_red);
+    if (threadIdx.x == 0) pp[n_blocks + blockIdx.y * t.gx[level] + blockIdx.x] = s;
 }
 
 struct ds_geom {
@@ -558,9 +567,11 @@ static int dssim_allocate(ce_batch *b)
         CE_HIP(ctx, hipMalloc(&b->ds_rmu[l], rb));
         CE_HIP(ctx, hipMalloc(&b->ds_rsq[l], rb));
     }
-    CE_HIP(ctx, hipMalloc(&b->ds_map, (size_t)b->max_pairs * p0 * sizeof(float)));
-    // partial sums per (pair, level): the absdev kernel's blocks, or the compare kernel's strip tiles (>= 8 rows each)
-    b->ds_blocks = std::max(((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4), ((b->ds[0].w + CE_DSSIM_STRIP - 1) / CE_DSSIM_STRIP) * ((b->ds[0].h + 7) / 8));
+    size_t map_floats = 0;  // every level's SSIM maps stay until the tail kernels have run
+    for (int l = 0; l < n; l++) map_floats += (size_t)b->max_pairs * b->ds[l].plane;
+    CE_HIP(ctx, hipMalloc(&b->ds_map, map_floats * sizeof(float)));
+    // partial sums per (pair, level): the absdev kernel's blocks, or the compare kernel's strip tiles (>= 2 rows each)
+    b->ds_blocks = std::max(((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4), ((b->ds[0].w + CE_DSSIM_STRIP - 1) / CE_DSSIM_STRIP) * ((b->ds[0].h + 1) / 2));
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->ds_level_scores, (size_t)b->max_pairs * CE_DSSIM_SCALES * sizeof(double)));  // avg, then score
     return CE_OK;
@@ -600,6 +611,8 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         return e && std::string(e) == "tile";
     }();
     ds_geom g{};
+    ds_tail tail{};
+    size_t map_off = 0;
     for (int l = 0; l < b->ds_levels; l++) {
         const auto &d = b->ds[l];
         const bool has_next = l + 1 < b->ds_levels;
@@ -622,19 +635,25 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         if (tile_compare) {
             if ((rc = ce_build_xcd_list(b, n_pairs, tiles.x * tiles.y, &b->ds_work[l])) != CE_OK) return rc;
             CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, (const float *)b->ds_img,
-                      (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map,
+                      (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map + map_off,
                       b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
             n_part = tiles.x * tiles.y;
         } else {
-            if ((rc = ce_dssim_compare_stream(b, l, n_pairs, &n_part)) != CE_OK) return rc;
+            if ((rc = ce_dssim_compare_stream(b, l, n_pairs, b->ds_map + map_off, &n_part)) != CE_OK) return rc;
         }
-        CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs), dim3(TPB), 0, b->ds_part, b->ds_level_scores, d.w, d.h, (uint32_t)l,
-                  (uint32_t)b->ds_levels, b->ds_blocks, n_part);
-        const dim3 gp((d.w + 63) / 64, (d.h + AD_ROWS - 1) / AD_ROWS, n_pairs);
-        CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, b->ds_map, b->ds_level_scores, b->ds_part, d.w, d.h,
-                  d.pitch, d.plane, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks);
+        tail.w[l] = d.w, tail.h[l] = d.h, tail.pitch[l] = d.pitch, tail.plane[l] = d.plane, tail.n_part[l] = n_part;
+        tail.gx[l] = (d.w + 63) / 64;
+        tail.map_off[l] = map_off;
+        map_off += (size_t)b->max_pairs * d.plane;
         g.npix[l] = d.w * d.h;
-        g.nblk[l] = gp.x * gp.y;
+        g.nblk[l] = tail.gx[l] * ((d.h + AD_ROWS - 1) / AD_ROWS);
+    }
+    {
+        const uint32_t nl = (uint32_t)b->ds_levels;
+        CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs, nl), dim3(TPB), 0, b->ds_part, b->ds_level_scores, tail, nl, b->ds_blocks);
+        const dim3 gp(tail.gx[0], (tail.h[0] + AD_ROWS - 1) / AD_ROWS, n_pairs * nl);
+        CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, (const float *)b->ds_map, b->ds_level_scores, b->ds_part, tail, nl,
+                  b->ds_blocks);
     }
     if (b->keep_ref_pyramid && !cached) {
         b->ds_ref_src = d_refs;

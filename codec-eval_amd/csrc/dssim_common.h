@@ -51,5 +51,5 @@ __device__ __forceinline__ void rgb_to_lab(float r, float g, float b, float &L, 
 
 // Dssim::create_image of level `level` for the image slots z0 .. n_slots - 1 (references first; dssim_stream.hip)
 int ce_dssim_create_stream(ce_batch *b, int level, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs, uint32_t z0);
-// Dssim::compare of level `level` for the first n_pairs pairs (dssim_stream.hip); *n_part = partial sums written per pair
-int ce_dssim_compare_stream(ce_batch *b, int level, uint32_t n_pairs, uint32_t *n_part);
+// Dssim::compare of level `level` for the first n_pairs pairs (dssim_stream.hip); level_map = the level's SSIM maps (one plane per pair); *n_part = partial sums written per pair
+int ce_dssim_compare_stream(ce_batch *b, int level, uint32_t n_pairs, float *level_map, uint32_t *n_part);

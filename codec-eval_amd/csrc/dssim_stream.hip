@@ -455,6 +455,9 @@ uint32_t stream_rows(uint32_t strips, uint32_t h, uint32_t n_images)
     }();
     uint32_t rows = 64;
     while (rows > 8 && (size_t)strips * ((h + rows - 1) / rows) * n_images < min_waves) rows /= 2;
+    // a launch that cannot fill the chip anyway is bound by the latency of ONE wave's walk (rows + 4 steps of ~370 dependent
+    // instructions): shorter walks, more waves
+    while (rows > 2 && (size_t)strips * ((h + rows - 1) / rows) * n_images < 1024) rows /= 2;
     return rows;
 }
 
@@ -501,7 +504,7 @@ int ce_dssim_create_stream(ce_batch *b, int l, const uint8_t *d_refs, uint32_t n
     return CE_OK;
 }
 
-int ce_dssim_compare_stream(ce_batch *b, int l, uint32_t n_pairs, uint32_t *n_part)
+int ce_dssim_compare_stream(ce_batch *b, int l, uint32_t n_pairs, float *level_map, uint32_t *n_part)
 {
     ce_ctx *ctx = b->ctx;
     const auto &d = b->ds[l];
@@ -511,7 +514,7 @@ int ce_dssim_compare_stream(ce_batch *b, int l, uint32_t n_pairs, uint32_t *n_pa
     if (rc != CE_OK) return rc;
     CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare_stream, dim3(b->ds_gwork[l].len / CS_WAVES), dim3(CS_WAVES * 64), 0,
               (const float *)b->ds_img, (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l],
-              b->d_pair_ref, b->ds_map, b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks,
+              b->d_pair_ref, level_map, b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks,
               (const uint2 *)b->ds_gwork[l].d, strips, rows);
     *n_part = strips * ((d.h + rows - 1) / rows);
     return CE_OK;

@@ -8,6 +8,8 @@
 //
 // Inner loop: 16 bytes per lane per image; sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab with
 // three v_dot4_u32_u8 per dword pair (no per-byte unpacking).
+#include <algorithm>
+
 #include "ce_internal.h"
 
 namespace {
@@ -87,7 +89,10 @@ int ce_launch_psnr(ce_batch *b, const uint8_t *d_refs, uint32_t n_pairs)
     CE_LAUNCH(ctx, "psnr_clear", k_psnr_clear, dim3((n_pairs + 255) / 256), dim3(256), 0, b->d_scores, n_pairs);
     size_t work = (b->img_bytes + 15) / 16;
     uint32_t blocks = (uint32_t)((work + kThreads - 1) / kThreads);
-    if (blocks > kBlocksPerPair) blocks = kBlocksPerPair;
+    // a few pairs alone cannot fill the chip with 64 blocks each and a block's loop is then pure latency (one 768x512 pair:
+    // 48 us with 64 blocks): up to one 16-byte piece per thread while the launch stays under ~4096 blocks
+    const uint32_t cap = std::max<uint32_t>(kBlocksPerPair, 4096u / n_pairs);
+    if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     CE_LAUNCH(ctx, "psnr_sse", k_psnr_sse, dim3(blocks, n_pairs), dim3(kThreads), 0, d_refs, b->d_tests, b->d_pair_ref,
               b->d_scores, b->img_bytes);
