@@ -288,6 +288,9 @@ void ce_ctx_destroy(ce_ctx *ctx)
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
+    hipFree(ctx->leaf_d_in);
+    hipFree(ctx->leaf_d_out);
+    if (ctx->leaf_h) hipHostFree(ctx->leaf_h);
     hipFree(ctx->d_lut_ssim2);
     hipFree(ctx->d_lut_powf);
     hipFree(ctx->d_xyb_thresh);
@@ -1247,28 +1250,50 @@ int ce_calculate_butteraugli(ce_ctx *ctx, const uint8_t *reference, size_t refer
                 out);
 }
 
+// leaf scratch (ce_internal.h): device buffers of at least in_bytes / out_bytes and a pinned staging buffer of the larger
+static int leaf_scratch(ce_ctx *ctx, size_t in_bytes, size_t out_bytes)
+{
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    auto grow = [&](uint8_t *&p, size_t &cap, size_t want, bool host) -> int {
+        if (cap >= want) return CE_OK;
+        if (p) CE_HIP(ctx, host ? hipHostFree(p) : hipFree(p));
+        p = nullptr;
+        cap = 0;
+        const size_t sz = want + want / 4;  // a little head room: a sweep over nearby shapes does not reallocate each time
+        CE_HIP(ctx, host ? hipHostMalloc((void **)&p, sz, hipHostMallocDefault) : hipMalloc((void **)&p, sz));
+        cap = sz;
+        return CE_OK;
+    };
+    int rc = grow(ctx->leaf_d_in, ctx->leaf_in_cap, in_bytes, false);
+    if (rc == CE_OK) rc = grow(ctx->leaf_d_out, ctx->leaf_out_cap, out_bytes, false);
+    if (rc == CE_OK) rc = grow(ctx->leaf_h, ctx->leaf_h_cap, std::max(in_bytes, out_bytes), true);
+    return rc;
+}
+
+// host image in -> kernel -> host image out through the leaf scratch, everything on the context's stream
+static int leaf_roundtrip(ce_ctx *ctx, const void *in, size_t in_bytes, void *out, size_t out_bytes,
+                          const std::function<int(uint8_t *, uint8_t *)> &launch)
+{
+    int rc = leaf_scratch(ctx, in_bytes, out_bytes);
+    if (rc != CE_OK) return rc;
+    std::memcpy(ctx->leaf_h, in, in_bytes);
+    CE_HIP(ctx, hipMemcpyAsync(ctx->leaf_d_in, ctx->leaf_h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch(ctx->leaf_d_in, ctx->leaf_d_out);
+    if (rc != CE_OK) return rc;
+    CE_HIP(ctx, hipMemcpyAsync(ctx->leaf_h, ctx->leaf_d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out, ctx->leaf_h, out_bytes);
+    return CE_OK;
+}
+
 int ce_xyb_roundtrip(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height, uint8_t *out)
 {
     if (!ctx || !rgb || !out) return CE_ERR_INVALID_ARG;
     if (rgb_len != width * height * 3)
         return fail(ctx, CE_ERR_BAD_LENGTH, "Buffer size mismatch");  // xyb.rs:227
     if (rgb_len == 0) return CE_OK;
-    CE_HIP(ctx, hipSetDevice(ctx->device));
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    CE_HIP(ctx, hipMalloc(&d_in, rgb_len));
-    if (hipMalloc(&d_out, rgb_len) != hipSuccess) {
-        hipFree(d_in);
-        return fail(ctx, CE_ERR_BACKEND, "hipMalloc failed");
-    }
-    int rc = CE_OK;
-    if (hipMemcpy(d_in, rgb, rgb_len, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "H2D failed");
-    if (rc == CE_OK) rc = ce_launch_xyb_roundtrip(ctx, d_in, d_out, width * height);
-    if (rc == CE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "sync failed");
-    if (rc == CE_OK && hipMemcpy(out, d_out, rgb_len, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(ctx, CE_ERR_BACKEND, "D2H failed");
-    hipFree(d_in);
-    hipFree(d_out);
-    return rc;
+    return leaf_roundtrip(ctx, rgb, rgb_len, out, rgb_len,
+                          [&](uint8_t *d_in, uint8_t *d_out) { return ce_launch_xyb_roundtrip(ctx, d_in, d_out, width * height); });
 }
 
 int ce_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size_t width, size_t height,
@@ -1278,23 +1303,9 @@ int ce_rgb8_to_dssim_image(ce_ctx *ctx, const uint8_t *rgb, size_t rgb_len, size
     if (rgb_len != width * height * 3) return fail(ctx, CE_ERR_BAD_LENGTH, "Buffer size mismatch");
     const size_t n = width * height;
     if (n == 0) return CE_OK;
-    CE_HIP(ctx, hipSetDevice(ctx->device));
-    uint8_t *d_in = nullptr;
-    float *d_out = nullptr;
-    CE_HIP(ctx, hipMalloc(&d_in, rgb_len));
-    if (hipMalloc(&d_out, n * 4 * sizeof(float)) != hipSuccess) {
-        hipFree(d_in);
-        return fail(ctx, CE_ERR_BACKEND, "hipMalloc failed");
-    }
-    int rc = CE_OK;
-    if (hipMemcpy(d_in, rgb, rgb_len, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "H2D failed");
-    if (rc == CE_OK) rc = ce_launch_rgb8_to_dssim_image(ctx, d_in, d_out, n);
-    if (rc == CE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, CE_ERR_BACKEND, "sync failed");
-    if (rc == CE_OK && hipMemcpy(rgba_out, d_out, n * 4 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(ctx, CE_ERR_BACKEND, "D2H failed");
-    hipFree(d_in);
-    hipFree(d_out);
-    return rc;
+    return leaf_roundtrip(ctx, rgb, rgb_len, rgba_out, n * 4 * sizeof(float), [&](uint8_t *d_in, uint8_t *d_out) {
+        return ce_launch_rgb8_to_dssim_image(ctx, d_in, reinterpret_cast<float *>(d_out), n);
+    });
 }
 
 // ---- reference handle -------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ce_metrics.h"
+#include "ce_metrics_debug.h"
 
 #define CE_MAX_SCALES 6      // SSIMULACRA2 pyramid depth
 #define CE_SSIM2_STREAMS 5   // blur(a), blur(b), blur(a*a), blur(b*b), blur(a*b)
@@ -75,6 +76,11 @@ struct ce_ctx {
     // bucket through them in chunks so that the upload of one chunk overlaps the kernels of the previous one)
     static constexpr uint32_t kPoolRing = 3;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ce_batch *> shape_pool;
+
+    // grow-only scratch of the leaf entry points that take one host image and return one (ce_xyb_roundtrip,
+    // ce_rgb8_to_dssim_image): device in / out and a page-locked staging buffer, kept between calls
+    uint8_t *leaf_d_in = nullptr, *leaf_d_out = nullptr, *leaf_h = nullptr;
+    size_t leaf_in_cap = 0, leaf_out_cap = 0, leaf_h_cap = 0;
 
     // two parked host threads that enqueue the other metric chains of a forked batch (ce_api.cpp: ce_fork_helpers); made on
     // the first forked launch, joined by ce_ctx_destroy

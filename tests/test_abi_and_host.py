@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "ce_metrics.h")).read()
+    """Every function any header under include/ declares (the boundary, ce_metrics.h, and the test hooks, ce_metrics_debug.h)."""
+    inc = os.path.join(ROOT, "include")
+    text = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ce_[a-z0-9_]+)\s*\(", text)))
 
@@ -20,12 +22,14 @@ def _declared_functions():
 def test_header_is_plain_c(tmp_path):
     """extern "C", plain pointers and sizes: the header must compile as C99 and as C++."""
     src = tmp_path / "t.c"
-    src.write_text('#include "ce_metrics.h"\nint main(void){ce_scores s; (void)s; return CE_OK;}\n')
+    src.write_text('#include "ce_metrics.h"\n#include "ce_metrics_debug.h"\nint main(void){ce_scores s; (void)s; return CE_OK;}\n')
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "t.o")])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "t2.o")])
-    text = open(os.path.join(inc, "ce_metrics.h")).read()
+    text = open(os.path.join(inc, "ce_metrics.h")).read() + open(os.path.join(inc, "ce_metrics_debug.h")).read()
     assert "torch" not in text.lower().replace("no torch", "") and "std::" not in text
+    # the boundary itself declares no test hook
+    assert "ce_debug_" not in re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, "ce_metrics.h")).read(), flags=re.S)
 
 
 def test_library_exports_every_declared_symbol(ce):

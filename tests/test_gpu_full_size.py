@@ -40,17 +40,22 @@ def test_4k_pair_every_metric_against_the_oracle(gpu_ctx, oracle, ce, workloads)
 
 
 def test_4k_batch_properties(gpu_ctx, ce, workloads):
-    n = 4
-    g = workloads.uhd_pairs(n, seed0=2100)
+    """BASELINE configs[2] at its full batch: 16 pairs of 3840x2160 resident at once (4 references x 4 qualities; ~24 GB of
+    working planes), Butteraugli + SSIMULACRA2."""
+    n_refs, quals = 4, (85, 70, 92, 60)
+    refs = [workloads.make_reference(W, H, 2100 + i) for i in range(n_refs)]
+    pairs = [(i, workloads.distort(refs[i], q)) for i in range(n_refs) for q in quals]
+    n = len(pairs)
+    assert n == 16
     cfg = ce.MetricConfig(butteraugli=True, ssimulacra2=True)
-    b = ce.Batch(gpu_ctx, W, H, n, n + 3)
-    for i, r in enumerate(g.references):
+    b = ce.Batch(gpu_ctx, W, H, n_refs, n + 3)
+    for i, r in enumerate(refs):
         b.set_reference(i, r)
-    for k, (ri, t) in enumerate(g.pairs):
+    for k, (ri, t) in enumerate(pairs):
         b.set_test(k, ri, t)
     # extra slots: an identical pair, and reference 0 at two more distortion strengths
-    b.set_test(n, 0, g.references[0])
-    strong, weak = workloads.distort(g.references[0], 40), workloads.distort(g.references[0], 97)
+    b.set_test(n, 0, refs[0])
+    strong, weak = workloads.distort(refs[0], 40), workloads.distort(refs[0], 97)
     b.set_test(n + 1, 0, strong)
     b.set_test(n + 2, 0, weak)
     s = b.run(n + 3, cfg)
@@ -58,11 +63,16 @@ def test_4k_batch_properties(gpu_ctx, ce, workloads):
     assert s[n].butteraugli == 0.0 and s[n].ssimulacra2 == 100.0  # identity
     assert s[n + 1].butteraugli > s[0].butteraugli > s[n + 2].butteraugli > 0.0  # q40 worse than q85 worse than q97
     assert s[n + 1].ssimulacra2 < s[0].ssimulacra2 < s[n + 2].ssimulacra2 < 100.0
+    # within a reference the scores follow the quality: q60 < q70 < q85 < q92
+    for i in range(n_refs):
+        by_q = {q: s[4 * i + j] for j, q in enumerate(quals)}
+        assert by_q[60].ssimulacra2 < by_q[70].ssimulacra2 < by_q[85].ssimulacra2 < by_q[92].ssimulacra2
+        assert by_q[60].butteraugli > by_q[70].butteraugli > by_q[85].butteraugli > by_q[92].butteraugli
     # batch == single call, bit for bit (pairs never interact)
-    single = gpu_ctx.calculate_metrics(g.references[1], g.pairs[1][1], W, H, cfg)
-    assert (single.butteraugli, single.ssimulacra2) == (s[1].butteraugli, s[1].ssimulacra2)
+    single = gpu_ctx.calculate_metrics(refs[1], pairs[5][1], W, H, cfg)
+    assert (single.butteraugli, single.ssimulacra2) == (s[5].butteraugli, s[5].ssimulacra2)
     # permuting the pairs permutes the scores
-    for k, (ri, t) in enumerate(reversed(g.pairs)):
+    for k, (ri, t) in enumerate(reversed(pairs)):
         b.set_test(k, ri, t)
     s2 = b.run(n, cfg)
     assert [(x.butteraugli, x.ssimulacra2) for x in s2] == [(x.butteraugli, x.ssimulacra2) for x in reversed(s[:n])]

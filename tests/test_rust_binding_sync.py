@@ -6,7 +6,7 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = open(os.path.join(ROOT, "include", "ce_metrics.h")).read()
+HEADER = open(os.path.join(ROOT, "include", "ce_metrics.h")).read() + open(os.path.join(ROOT, "include", "ce_metrics_debug.h")).read()
 SYS = open(os.path.join(ROOT, "bindings", "rust", "codec-eval-hip", "src", "sys.rs")).read()
 
 
