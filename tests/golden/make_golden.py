@@ -34,6 +34,11 @@ CASES = [  # name, w, h, seed, kind, quality, 4:2:0
     ("wide301x9_q70", 301, 9, 18, "natural", 70, False),
     ("tall9x301_q70", 9, 301, 19, "natural", 70, False),
     ("odd257x129_q30_420", 257, 129, 20, "natural", 30, True),
+    # the shapes every benchmark line uses (BASELINE configs[1] / configs[3]): SSIMULACRA2's round-off is a random walk ALONG THE
+    # LINE, so a crate run pins the recursion only at the line lengths it is run on.  Same seeds as the
+    # first reference of bench.py's Kodak and CID22 grids.
+    ("kodak768x512_q75", 768, 512, 1000, "natural", 75, False),
+    ("cid512x512_q50_420", 512, 512, 3000, "natural", 50, True),
 ]
 
 

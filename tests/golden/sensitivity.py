@@ -33,6 +33,8 @@ LEDGER = {
     "dssim_f32_final": ("dssim", "scale weighting and 1/ssim - 1 in f64", "in f32, widened by f64::from (dssim.rs:70)"),
     "ba_malta_f32": ("butteraugli", "Malta asymmetry term in f64 (as libjxl)", "in f32"),
     "ba_libm_log2": ("butteraugli", "Gamma() uses the lineage's FastLog2f", "libm log2f"),
+    "ba_blur_fma": ("butteraugli", "taps of the long separable blurs: multiply, then add (two roundings, lineage)",
+                    "one fused multiply-add per tap (measured on the device in round 3: +3 % throughput; NOT adopted - see the soak run in profiles/r03_experiments.md section 3)"),
     "ba_l2_early": ("butteraugli", "L2DiffAsymmetric(hf) / L2Diff(mf) of X and Y join block_diff_ac after the three Malta bands (lineage call order)",
                     "between the bands: uhf, L2asym(hf), hf, L2(mf), mf - the same in-place accumulations in the order the device's fused kernel meets the bands (what the DEVICE does, with ba_malta_f32)"),
 }
