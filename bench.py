@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-per-metric", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-per-call", action="store_true")
+    ap.add_argument("--no-kodak-only", action="store_true", help="config 0: skip the Kodak-grid-alone leg (profiler runs: every launch of the process then belongs to the main workload)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, config 0: skip the fixed-grid (strong scaling) leg")
     ap.add_argument("--all-events", action="store_true", help="events around every kernel in the timed region, not only the dominant one")
     ap.add_argument("--serial", action="store_true",
@@ -331,7 +332,10 @@ def main():
     import codec_eval_amd as ce  # loads the library; no HIP call until a context is made
 
     # ---- the workload, generated by a fork pool BEFORE anything initialises HIP in this process ---------------------------
-    wl.set_generation_workers(max(2, min(16, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
+    # (not under a profiler: rocprofv3's preloaded tool library has initialised the GPU before this program starts, and a
+    # process forked from there has hung at exit - the generation is then serial, use --refs / --quick to keep it short)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
+    wl.set_generation_workers(0 if profiled else max(2, min(16, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))))
     t_gen = time.perf_counter()
     wkl = Workload(args.config, args, rank, world, ce, wl, sh)
     strong_wkl = None
@@ -570,7 +574,7 @@ def main():
 
     # ---- Kodak grid alone: rounds 1-2's headline, for continuity (config 0, N = 1) ------------------------------------------------------
     kodak_launches = [l for l in launches_main if l[2] == "kodak"]
-    if args.config == 0 and world == 1 and kodak_launches and len(kodak_launches) < len(launches_main):
+    if args.config == 0 and world == 1 and kodak_launches and len(kodak_launches) < len(launches_main) and not args.no_kodak_only:
         kw = Workload.__new__(Workload)
         kw.__dict__.update(wkl.__dict__)
         kw.launches = kodak_launches
