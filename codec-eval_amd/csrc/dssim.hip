@@ -432,6 +432,7 @@ __global__ __launch_bounds__(TPB, 3) void k_dssim_compare(const float *__restric
 // launches, each ~4.5 us on the critical path of a single-pair call) ------------------------------------------------------
 struct ds_tail {
     uint32_t w[CE_DSSIM_SCALES], h[CE_DSSIM_SCALES], pitch[CE_DSSIM_SCALES], n_part[CE_DSSIM_SCALES], gx[CE_DSSIM_SCALES];
+    uint32_t blk_end[CE_DSSIM_SCALES];  // absdev blocks of levels 0 .. l, running total (the launch's x extent is the last one)
     size_t plane[CE_DSSIM_SCALES], map_off[CE_DSSIM_SCALES];  // the level's SSIM maps start at map + map_off[l], one plane per pair
 };
 
@@ -458,28 +459,32 @@ __global__ __launch_bounds__(TPB) void k_dssim_avg(const double *__restrict__ pa
     }
 }
 
-// mean absolute deviation of the SSIM map from avg; grid = level 0's blocks x (pairs x levels), a level's surplus blocks leave
+// mean absolute deviation of the SSIM map from avg; 1-D grid: per pair, the blocks of all levels one after the other
 constexpr int AD_ROWS = 32;  // rows per block
 __global__ __launch_bounds__(TPB) void k_dssim_absdev(const float *__restrict__ map, const double *__restrict__ avg_in,
                                                       double *__restrict__ part, ds_tail t, uint32_t n_levels, uint32_t n_blocks)
 {
     __shared__ double s_red[TPB / 64];
-    const uint32_t p = blockIdx.z / n_levels, level = blockIdx.z % n_levels;
-    const uint32_t w = t.w[level], h = t.h[level], pitch = t.pitch[level];
-    if (blockIdx.x >= t.gx[level] || blockIdx.y * AD_ROWS >= h) return;  // block-uniform
+    const uint32_t per_pair = t.blk_end[n_levels - 1], p = blockIdx.x / per_pair, bi = blockIdx.x % per_pair;
+    uint32_t level = 0, first = 0;
+#pragma unroll
+    for (int l = 0; l + 1 < CE_DSSIM_SCALES; l++)
+        if (l + 1 < (int)n_levels && bi >= t.blk_end[l]) level = l + 1, first = t.blk_end[l];
+    const uint32_t w = t.w[level], h = t.h[level], pitch = t.pitch[level], gx = t.gx[level];
+    const uint32_t bx = (bi - first) % gx, by = (bi - first) / gx;
     double *pp = part + ((size_t)p * n_levels + level) * 2 * n_blocks;
     const double avg = avg_in[(size_t)p * n_levels + level];
     const float *m = map + t.map_off[level] + (size_t)p * t.plane[level];
     // block = 64 columns x 32 rows, a thread walks 8 rows (stride 4): one block reduction per 2048 pixels
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t x = bx * 64 + (threadIdx.x & 63);
     double val = 0.0;
 #pragma unroll
     for (int k = 0; k < AD_ROWS / 4; k++) {
-        const uint32_t y = blockIdx.y * AD_ROWS + 4 * k + (threadIdx.x >> 6);
+        const uint32_t y = by * AD_ROWS + 4 * k + (threadIdx.x >> 6);
         if (x < w && y < h) val += fabs(avg - (double)m[(size_t)y * pitch + x]);
     }
     const double s = block_sum(val, s_red);
-    if (threadIdx.x == 0) pp[n_blocks + blockIdx.y * t.gx[level] + blockIdx.x] = s;
+    if (threadIdx.x == 0) pp[n_blocks + by * gx + bx] = s;
 }
 
 struct ds_geom {
@@ -647,11 +652,12 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
         map_off += (size_t)b->max_pairs * d.plane;
         g.npix[l] = d.w * d.h;
         g.nblk[l] = tail.gx[l] * ((d.h + AD_ROWS - 1) / AD_ROWS);
+        tail.blk_end[l] = (l ? tail.blk_end[l - 1] : 0u) + g.nblk[l];
     }
     {
         const uint32_t nl = (uint32_t)b->ds_levels;
         CE_LAUNCH(ctx, "dssim_avg", k_dssim_avg, dim3(n_pairs, nl), dim3(TPB), 0, b->ds_part, b->ds_level_scores, tail, nl, b->ds_blocks);
-        const dim3 gp(tail.gx[0], (tail.h[0] + AD_ROWS - 1) / AD_ROWS, n_pairs * nl);
+        const dim3 gp(tail.blk_end[nl - 1] * n_pairs);
         CE_LAUNCH(ctx, "dssim_absdev", k_dssim_absdev, gp, dim3(TPB), 0, (const float *)b->ds_map, b->ds_level_scores, b->ds_part, tail, nl,
                   b->ds_blocks);
     }
