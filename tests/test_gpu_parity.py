@@ -394,7 +394,11 @@ def test_dssim_reference_cases(gpu_ctx, oracle, ce):
 
 
 DSSIM_SHAPES = [(1, 1), (3, 2), (7, 9), (8, 8), (15, 17), (20, 20), (64, 64), (100, 100), (101, 77), (255, 129), (768, 512), (512, 768),
-                (33, 33), (65, 31), (32, 96)]  # one pixel over / under the 32 x 32 tile
+                (33, 33), (65, 31), (32, 96),  # one pixel over / under the 32 x 32 tile (CE_DSSIM_*=tile kernels)
+                # the streaming kernels' strips: 60 output columns per wave for a distorted image / a pair, 56 for a reference,
+                # walks of 2 .. 64 rows - one column / row under, on and over their edges, and degenerate strips
+                (59, 9), (60, 10), (61, 33), (62, 3), (119, 66), (120, 64), (121, 65), (56, 8), (57, 130), (112, 5), (113, 17),
+                (300, 2), (2, 300), (1, 70), (70, 1), (4, 4), (5, 63)]
 
 
 @pytest.mark.parametrize("w,h", DSSIM_SHAPES)

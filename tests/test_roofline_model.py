@@ -58,3 +58,17 @@ def test_step_bytes_names_are_launch_names():
         src += open(os.path.join(root, f)).read()
     names = set(re.findall(r'CE_LAUNCH(?:_ON)?\(ctx,(?: s\d,)? "([a-z0-9_\-A-Z]+)"', src)) | {"ba_blur_h13", "ba_blur_v13"}
     assert expected <= names, expected - names
+
+
+def test_round2_model_is_frozen():
+    """`pipeline_frac_r02_model` prices every round's step against round 2's byte model.  The frozen table
+    must reproduce BENCH_r02's 16.56 GB per step of the Kodak grid (72 pairs, three metrics) to the byte, and config 5's."""
+    kodak = [rf.Bucket(768, 512, 18, 54), rf.Bucket(512, 768, 6, 18)]
+    three = ["ssimulacra2", "dssim", "butteraugli"]
+    assert rf.step_bytes_r02_model(kodak, three) == 16557613056.0
+    # while the current kernels' model is unchanged it equals the frozen one, metric by metric
+    for m in three:
+        assert rf.step_bytes_r02_model(kodak, [m]) == sum(rf.step_bytes(kodak, [m]).values())
+    dense = [rf.Bucket(512, 512, 15, 1500)]
+    allm = ["ssimulacra2", "dssim", "butteraugli", "psnr"]
+    assert rf.step_bytes_r02_model(dense, allm, True) == sum(rf.step_bytes(dense, allm, True).values())
