@@ -179,7 +179,6 @@ struct ce_batch {
     double *ds_part = nullptr; // [pairs][levels][2][blocks] partial sums (sum, abs-dev)
     double *ds_level_scores = nullptr;  // [pairs][levels]
     uint32_t ds_blocks = 0;
-    ce_xcd_list ds_work[CE_DSSIM_SCALES];  // k_dssim_compare's launch order, per level (CE_DSSIM_COMPARE=tile: round 2's LDS-tile kernel)
     ce_group_list ds_gwork[CE_DSSIM_SCALES];  // k_dssim_compare_stream's launch order, per level
     bool dssim_ready = false;
 

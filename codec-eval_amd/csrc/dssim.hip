@@ -6,14 +6,12 @@
 //     linear RGB -> normalised L*a*b*  ->  chroma planes pre-blurred (= img);  references also: mu = blur(img),
 //     sq = blur(img*img), kept per level for all their pairs (and across launches for a reference handle)
 //   per pair ("compare"):
-//     the distorted image's mu / sq and i12 = blur(img1*img2) from the one img tile the kernel loads anyway ->
-//     SSIM map over the channel-averaged statistics -> mean -> mean |avg - ssim|
-//   (a distorted image's mu / sq are used by exactly one compare: computing them there instead of in create_image
-//   saves their round trip through HBM - 48 B per pixel and level - and moves their arithmetic from the VALU-bound
-//   create kernels into the compare kernel, which waits on memory)
-// "blur" is the fixed 3x3 kernel applied twice with edge replication.  Every plane op keeps the
-// oracle's f32 operation order (oracle/dssim.c), so planes are bit-identical; sums are f64.
-// Build with -ffp-contract=off.
+//     the distorted image's mu / sq and i12 = blur(img1*img2) -> SSIM map over the channel-averaged statistics
+//   after the last level, for all levels at once: mean -> mean |avg - ssim| -> weighted score
+// "blur" is the fixed 3x3 kernel applied twice with edge replication.  The per-level kernels are the streaming kernels of
+// dssim_stream.hip (round 3; rounds 1-2 ran 32 x 32 LDS-tile kernels here: profiles/r03_experiments.md sections 1, 7); this
+// file holds the tail reductions, the working set and the launch sequence.  Every plane op keeps the oracle's f32 operation
+// order (oracle/dssim.c), so planes are bit-identical; sums are f64.  Build with -ffp-contract=off.
 #include <algorithm>
 #include <cstdlib>
 
@@ -40,211 +38,6 @@ __global__ __launch_bounds__(TPB) void k_rgb8_to_rgba_f32(const uint8_t *__restr
         out[i] = make_float4(s_lut[rgb[3 * i]], s_lut[rgb[3 * i + 1]], s_lut[rgb[3 * i + 2]], 1.0f);
 }
 
-// One 3x3 pass with edge replication, evaluated on an LDS region of width RW whose local (0,0) is global
-// (gx0, gy0).  The centre (lx, ly) must be inside the image; neighbours are clamped in GLOBAL coordinates,
-// which is exactly "replicate the edge of that pass's input".  SQ squares every tap (blur of the squared
-// image).  Summation order as in oracle/dssim.c: corners, edges, centre.
-// INTERIOR: the whole region lies inside the image (block-uniform), so no neighbour is clamped and the nine taps
-// are LDS reads at constant offsets from the centre.
-template <int RW, bool SQ, bool INTERIOR = false>
-__device__ __forceinline__ float pass3x3(const float *__restrict__ A, int lx, int ly, int gx0, int gy0, int w, int h)
-{
-    if (INTERIOR) {
-        const float *c = A + ly * RW + lx;
-        auto sqv = [](float v) { return SQ ? v * v : v; };
-        const float K0 = 0.095332f, K1 = 0.118095f, K4 = 0.146293f;
-        return (sqv(c[-RW - 1]) + sqv(c[-RW + 1]) + sqv(c[RW - 1]) + sqv(c[RW + 1])) * K0 +
-               (sqv(c[-RW]) + sqv(c[-1]) + sqv(c[1]) + sqv(c[RW])) * K1 + sqv(c[0]) * K4;
-    }
-    const int X = gx0 + lx, Y = gy0 + ly;
-    const int xm = max(X - 1, 0) - gx0, xp = min(X + 1, w - 1) - gx0;
-    const int ym = max(Y - 1, 0) - gy0, yp = min(Y + 1, h - 1) - gy0;
-    auto at = [&](int yy, int xx) {
-        const float v = A[yy * RW + xx];
-        return SQ ? v * v : v;
-    };
-    const float K0 = 0.095332f, K1 = 0.118095f, K4 = 0.146293f;
-    return (at(ym, xm) + at(ym, xp) + at(yp, xm) + at(yp, xp)) * K0 + (at(ym, lx) + at(ly, xm) + at(ly, xp) + at(yp, lx)) * K1 +
-           at(ly, lx) * K4;
-}
-
-
-// ---- Dssim::create_image for one level, fused: 32x32 tile + halo 4 in LDS ------------------------------------
-// linear RGB (level 0: sRGB u8 through the host-powf table) -> L*a*b* -> chroma pre-blur (2 passes) ->
-// mu = blur(img) (2 passes), sq = blur(img*img) (2 passes); also the next level's linear RGB.
-// Writes img, mu, sq (9 planes) for the tile; every intermediate lives in LDS only.
-constexpr int DT = 32, DR = DT + 8;
-
-// The elements of an R x R LDS region that lie at least M away from its border, TPB at a time.  The loop runs over ALL
-// R * R elements with a margin test, so consecutive lanes always touch consecutive LDS words: looping over the compact
-// (R - 2M)^2 index space instead saves a tenth of the wave-instructions but makes every second half-wave straddle two
-// region rows (R - 2M = 34 lanes of one, then the next), a two-way bank conflict on every access - measured in round 2:
-// SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS 0.00 -> 1.0 (compare), -> 1.8 (create), no time gained.
-#define CE_MARGIN_LOOP(R, M, i, lx, ly)                                                                               \
-    _Pragma("unroll 1") for (int i = threadIdx.x, lx = i % (R), ly = i / (R); i < (R) * (R); i += TPB, lx = i % (R), ly = i / (R)) \
-        if (lx >= (M) && lx < (R) - (M) && ly >= (M) && ly < (R) - (M))
-
-// FULL = a reference slot (img, mu, sq; region RW = tile + 8); otherwise a distorted image (img only: S1, S2 and the img
-// store; its region is the tile + 4 the two chroma passes need - a quarter less L*a*b* work than the reference's 40 x 40)
-template <bool IN, bool FULL, int RW>
-__device__ __forceinline__ void dssim_create_stages(float (&P)[6][DR * DR], float *__restrict__ img, float *__restrict__ mu,
-                                                    float *__restrict__ sq, const lvl_geom &g, uint32_t slot, int x0, int y0)
-{
-    constexpr int HL = (RW - DT) / 2;
-    static_assert(FULL ? HL == 4 : HL == 2, "halo");
-    const int w = (int)g.w, h = (int)g.h, gx0 = x0 - HL, gy0 = y0 - HL;
-    auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
-    // Six LDS planes are enough (38 KB, four blocks per CU instead of two): planes are reused as soon as their
-    // contents are dead, and mu / sq are produced one after the other through the same three planes.
-    // S1: chroma pre-blur pass 1 (margin 1): P1,P2 -> P3,P4
-    CE_MARGIN_LOOP(RW, 1, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-            P[3][i] = pass3x3<RW, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<RW, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S2: chroma pre-blur pass 2 (margin 2): P3,P4 -> P1,P2 (their old contents are dead) ; img = (P0, P1, P2)
-    CE_MARGIN_LOOP(RW, 2, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-            P[1][i] = pass3x3<RW, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
-            P[2][i] = pass3x3<RW, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    if (!FULL) {  // a distorted image: img is all that leaves (its mu / sq are formed by the compare kernel)
-        for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-            const int tx = i % DT, ty = i / DT, X = x0 + tx, Y = y0 + ty;
-            if (IN || (X < w && Y < h)) {
-                const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-                const int li = (ty + HL) * RW + tx + HL;
-                img[o] = P[0][li];
-                img[o + g.plane] = P[1][li];
-                img[o + 2 * g.plane] = P[2][li];
-            }
-        }
-        return;
-    }
-    // S3a: first pass of mu (margin 3): img -> P3,P4,P5
-    CE_MARGIN_LOOP(RW, 3, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-            P[3][i] = pass3x3<RW, false, IN>(P[0], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<RW, false, IN>(P[1], lx, ly, gx0, gy0, w, h);
-            P[5][i] = pass3x3<RW, false, IN>(P[2], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S4a: second pass of mu on the tile itself; write img and mu
-    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-        const int tx = i % DT, ty = i / DT, lx = tx + HL, ly = ty + HL, X = x0 + tx, Y = y0 + ty;
-        if (IN || (X < w && Y < h)) {
-            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-            const int li = ly * RW + lx;
-            img[o] = P[0][li];
-            img[o + g.plane] = P[1][li];
-            img[o + 2 * g.plane] = P[2][li];
-            mu[o] = pass3x3<RW, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
-            mu[o + g.plane] = pass3x3<RW, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
-            mu[o + 2 * g.plane] = pass3x3<RW, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S3b: first pass of sq = blur(img * img): img -> P3,P4,P5
-    CE_MARGIN_LOOP(RW, 3, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-            P[3][i] = pass3x3<RW, true, IN>(P[0], lx, ly, gx0, gy0, w, h);
-            P[4][i] = pass3x3<RW, true, IN>(P[1], lx, ly, gx0, gy0, w, h);
-            P[5][i] = pass3x3<RW, true, IN>(P[2], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // S4b: second pass of sq; write sq
-    for (int i = threadIdx.x; i < DT * DT; i += TPB) {
-        const int tx = i % DT, ty = i / DT, lx = tx + HL, ly = ty + HL, X = x0 + tx, Y = y0 + ty;
-        if (IN || (X < w && Y < h)) {
-            const size_t o = (size_t)slot * 3 * g.plane + (size_t)Y * g.pitch + X;
-            sq[o] = pass3x3<RW, false, IN>(P[3], lx, ly, gx0, gy0, w, h);
-            sq[o + g.plane] = pass3x3<RW, false, IN>(P[4], lx, ly, gx0, gy0, w, h);
-            sq[o + 2 * g.plane] = pass3x3<RW, false, IN>(P[5], lx, ly, gx0, gy0, w, h);
-        }
-    }
-}
-
-template <bool FROM_U8>
-__global__ __launch_bounds__(TPB) void k_dssim_create(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
-                                                      const float *__restrict__ lut, const float *__restrict__ lin_in,
-                                                      float *__restrict__ lin_out, float *__restrict__ img,
-                                                      float *__restrict__ rimg, float *__restrict__ rmu,
-                                                      float *__restrict__ rsq, lvl_geom g, lvl_geom gn, int has_next,
-                                                      size_t img_bytes, uint32_t n_refs_used, uint32_t max_refs, uint32_t z0)
-{
-    __shared__ float P[6][DR * DR];
-    __shared__ float s_lut[256];
-    if (FROM_U8) s_lut[threadIdx.x] = lut[threadIdx.x];
-    // z0 > 0: the references' planes of this level are cached (reference handle), only the distorted slots are built
-    const uint32_t z = blockIdx.z + z0, slot = slot_of(z, n_refs_used, max_refs);
-    // a reference's img / mu / sq go to its own per-level buffers (slot z there) so that they survive the level loop
-    // and the next launches; a distorted image's img goes to the shared per-launch buffer (slot = pair index)
-    const bool is_ref = z < n_refs_used;
-    const uint32_t oslot = is_ref ? z : z - n_refs_used;
-    const int w = (int)g.w, h = (int)g.h;
-    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT;
-    const uint8_t *src8 = nullptr;
-    if (FROM_U8) src8 = z < n_refs_used ? refs + (size_t)z * img_bytes : tests + (size_t)(z - n_refs_used) * img_bytes;
-    const float *srcf = lin_in + (size_t)slot * 3 * g.plane;
-    __syncthreads();
-    auto load_rgb = [&](int X, int Y, float &r, float &gg, float &b) {
-        if (FROM_U8) {
-            // 32-bit: DSSIM keeps > 300 B per pixel resident, so an image that fits the device is far below 2^32 / 3 pixels
-            const uint8_t *px = src8 + ((uint32_t)Y * (uint32_t)w + (uint32_t)X) * 3u;
-            r = s_lut[px[0]];
-            gg = s_lut[px[1]];
-            b = s_lut[px[2]];
-        } else {
-            const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
-            r = srcf[o];
-            gg = srcf[o + g.plane];
-            b = srcf[o + 2 * g.plane];
-        }
-    };
-    // next level: (a + b + c + d) * 0.25 over the tile's own 2x2 quads, floor sizes (odd last row/column dropped)
-    if (has_next) {
-        const int ox = x0 / 2 + (threadIdx.x & 15), oy = y0 / 2 + (threadIdx.x >> 4);
-        if (ox < (int)gn.w && oy < (int)gn.h) {
-            float q[4][3];
-#pragma unroll
-            for (int k = 0; k < 4; k++) load_rgb(2 * ox + (k & 1), 2 * oy + (k >> 1), q[k][0], q[k][1], q[k][2]);
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-                lin_out[((size_t)slot * 3 + c) * gn.plane + (size_t)oy * gn.pitch + ox] = (q[0][c] + q[1][c] + q[2][c] + q[3][c]) * 0.25f;
-        }
-    }
-    // S0: L*a*b* of the clamped region (tile + 4 for a reference, tile + 2 for a distorted image), then S1..S4: a block
-    // whose region is wholly inside the image takes the variant without clamping or bounds tests
-    auto region = [&](auto rw_tag, auto full_tag, float *oimg, float *omu, float *osq) {
-        constexpr int RW = decltype(rw_tag)::value;
-        constexpr bool FULL = decltype(full_tag)::value;
-        constexpr int HL = (RW - DT) / 2;
-        const int gx0 = x0 - HL, gy0 = y0 - HL;
-        for (int i = threadIdx.x; i < RW * RW; i += TPB) {
-            const int lx = i % RW, ly = i / RW;
-            const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
-            float r, gg, b;
-            load_rgb(X, Y, r, gg, b);
-            rgb_to_lab(r, gg, b, P[0][i], P[1][i], P[2][i]);
-        }
-        __syncthreads();
-        if (gx0 >= 0 && gy0 >= 0 && gx0 + RW <= w && gy0 + RW <= h)
-            dssim_create_stages<true, FULL, RW>(P, oimg, omu, osq, g, oslot, x0, y0);
-        else
-            dssim_create_stages<false, FULL, RW>(P, oimg, omu, osq, g, oslot, x0, y0);
-    };
-    if (is_ref)
-        region(std::integral_constant<int, DR>{}, std::true_type{}, rimg, rmu, rsq);
-    else
-        region(std::integral_constant<int, DT + 4>{}, std::false_type{}, img, nullptr, nullptr);
-}
-
 __device__ __forceinline__ double block_sum(double v, double *s_red)
 {
 #pragma unroll
@@ -256,176 +49,6 @@ __device__ __forceinline__ double block_sum(double v, double *s_red)
         for (int k = 0; k < TPB / 64; k++) t += s_red[k];
     __syncthreads();
     return t;
-}
-
-// ---- Dssim::compare for one level, fused: i12 = blur(img1*img2) in LDS (tile + halo 2), then compare_scale ----
-constexpr int CR = DT + 4;
-
-// (A variant in which a block walks ALL distorted images of one reference, so that the reference's nine planes are read
-// from cache after the first, was measured in round 2: 0.85 ms per step against 0.70 ms for this one-pair-per-block
-// form on the Kodak grid - the per-block loop with two barriers per distorted image costs more latency than the
-// reference re-reads cost bandwidth; with 24 x 16 tiles per image the blocks of consecutive pairs of a reference
-// already land on the same XCD, 384 = 0 mod 8.)
-// The distorted image's mu = blur(img2) and sq = blur(img2 * img2), and i12 = blur(img1 * img2): three two-pass 3x3 blurs
-// of the SAME 36x36 region (tile + halo 2), each the same pass3x3 sequence create_image runs for a reference (same taps,
-// same order, same edge replication: bit-identical to Dssim::create_image of the distorted image).  LDS planes: A = img2,
-// M = img1 * img2, T = first-pass output; M is reused as first-pass output once its own first pass is done:
-//   P1  T = pass(M)                       | barrier
-//   P2  s12 = pass(T);  M = pass(A)       | barrier
-//   P3  mu2 = pass(M);  T = pass(A^2)     | barrier
-//   P4  sq2 = pass(T);  SSIM
-// IN = the block's whole 36x36 region is inside the image (no clamping, no bounds tests).
-constexpr int CMP_OUT = DT * DT / TPB;  // output pixels per thread (4)
-// Left alone, the compiler reads the 27 taps of each of a thread's four pixels in P2 / P3 and SINKS the sums to their use
-// in P4, keeping (spilling) the raw taps instead of the 12 results: 290 registers, or 500 B of scratch under a cap.
-// CE_KEEP pins a result in a register where it is computed; the memory fence keeps one pixel's taps live at a time.
-#define CE_SCHED_FENCE() asm volatile("" ::: "memory")
-#define CE_KEEP(x) asm volatile("" : "+v"(x))
-struct cmp_stats {
-    float u1[CMP_OUT][3], q1[CMP_OUT][3];  // mu and blur(img^2) of the REFERENCE at this thread's pixels
-};
-
-template <bool IN>
-__device__ __forceinline__ double dssim_compare_stages(float (&A)[3][CR * CR], float (&M)[3][CR * CR], float (&T)[3][CR * CR],
-                                                       const float *__restrict__ r_mu, const float *__restrict__ r_sq,
-                                                       float *__restrict__ map, const lvl_geom &g, int x0, int y0)
-{
-    const int w = (int)g.w, h = (int)g.h, gx0 = x0 - 2, gy0 = y0 - 2;
-    const uint32_t plane = (uint32_t)g.plane;
-    auto inside = [&](int lx, int ly) { return gx0 + lx >= 0 && gx0 + lx < w && gy0 + ly >= 0 && gy0 + ly < h; };
-    float s12[CMP_OUT][3], u2[CMP_OUT][3], q2[CMP_OUT][3];
-    // P1
-    CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, false, IN>(M[c], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // P2
-#pragma unroll
-    for (int k = 0; k < CMP_OUT; k++) {
-        const int i = k * TPB + (int)threadIdx.x, tx = i % DT, ty = i / DT;
-        if (IN || (x0 + tx < w && y0 + ty < h)) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                s12[k][c] = pass3x3<CR, false, IN>(T[c], tx + 2, ty + 2, gx0, gy0, w, h);
-                CE_KEEP(s12[k][c]);
-            }
-        }
-        CE_SCHED_FENCE();
-    }
-    CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) M[c][i] = pass3x3<CR, false, IN>(A[c], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // P3
-#pragma unroll
-    for (int k = 0; k < CMP_OUT; k++) {
-        const int i = k * TPB + (int)threadIdx.x, tx = i % DT, ty = i / DT;
-        if (IN || (x0 + tx < w && y0 + ty < h)) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                u2[k][c] = pass3x3<CR, false, IN>(M[c], tx + 2, ty + 2, gx0, gy0, w, h);
-                CE_KEEP(u2[k][c]);
-            }
-        }
-        CE_SCHED_FENCE();
-    }
-    // the reference's mu / blur(img^2) at this thread's pixels: requested here, consumed in P4 behind the last first pass
-    // (pixels outside the image are clamped, never used)
-    cmp_stats st;
-#pragma unroll
-    for (int k = 0; k < CMP_OUT; k++) {
-        const int i = k * TPB + (int)threadIdx.x;
-        const int X = min(x0 + i % DT, w - 1), Y = min(y0 + i / DT, h - 1);
-        const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            st.u1[k][c] = r_mu[c * plane + o];
-            st.q1[k][c] = r_sq[c * plane + o];
-        }
-    }
-    CE_MARGIN_LOOP(CR, 1, i, lx, ly) {
-        if (IN || inside(lx, ly)) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) T[c][i] = pass3x3<CR, true, IN>(A[c], lx, ly, gx0, gy0, w, h);
-        }
-    }
-    __syncthreads();
-    // P4
-    double val = 0.0;
-#pragma unroll
-    for (int k = 0; k < CMP_OUT; k++) {
-        const int i = k * TPB + (int)threadIdx.x;
-        const int tx = i % DT, ty = i / DT, lx = tx + 2, ly = ty + 2, X = x0 + tx, Y = y0 + ty;
-        if (IN || (X < w && Y < h)) {
-            const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
-            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f, third = 1.0f / 3.0f;
-            float m11[3], m12[3], m22[3], s1[3], s2[3], s12c[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                q2[k][c] = pass3x3<CR, false, IN>(T[c], lx, ly, gx0, gy0, w, h);
-                const float u1 = st.u1[k][c], u2v = u2[k][c];
-                m11[c] = u1 * u1;
-                m12[c] = u1 * u2v;
-                m22[c] = u2v * u2v;
-                s1[c] = st.q1[k][c] - m11[c];
-                s2[c] = q2[k][c] - m22[c];
-                s12c[c] = s12[k][c] - m12[c];
-            }
-#define AVG3(v) (((v)[0] + (v)[1] + (v)[2]) * third)
-            const float mu1_sq = AVG3(m11), mu2_sq = AVG3(m22), mu1_mu2 = AVG3(m12);
-            const float sigma1_sq = AVG3(s1), sigma2_sq = AVG3(s2), sigma12 = AVG3(s12c);
-#undef AVG3
-            const float ssim = (2.0f * mu1_mu2 + c1) * (2.0f * sigma12 + c2) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2));
-            map[o] = ssim;
-            val += (double)ssim;
-        }
-        CE_SCHED_FENCE();
-    }
-    return val;
-}
-
-__global__ __launch_bounds__(TPB, 3) void k_dssim_compare(const float *__restrict__ img, const float *__restrict__ rimg,
-                                                       const float *__restrict__ rmu, const float *__restrict__ rsq,
-                                                       const uint32_t *__restrict__ pair_ref,
-                                                       float *__restrict__ map, double *__restrict__ part, lvl_geom g,
-                                                       uint32_t level, uint32_t n_levels, uint32_t n_blocks,
-                                                       const uint2 *__restrict__ work, uint32_t tiles_x)
-{
-    __shared__ float A[3][CR * CR], M[3][CR * CR], T[3][CR * CR];
-    __shared__ double s_red[TPB / 64];
-    // XCD-aware 1-D launch (ce_build_xcd_list): the pairs of a reference run the same tile back to back on one XCD
-    const uint2 wi = work[blockIdx.x];
-    if (wi.x == ~0u) return;  // padding entry
-    const uint32_t p = wi.y;
-    const int w = (int)g.w, h = (int)g.h;
-    const int x0 = (int)(wi.x % tiles_x) * DT, y0 = (int)(wi.x / tiles_x) * DT, gx0 = x0 - 2, gy0 = y0 - 2;
-    // block-uniform bases (scalar registers); everything a thread adds to them fits 32 bits (three planes of ONE image)
-    const float *r_img = rimg + (size_t)pair_ref[p] * 3 * g.plane, *r_mu = rmu + (size_t)pair_ref[p] * 3 * g.plane,
-                *r_sq = rsq + (size_t)pair_ref[p] * 3 * g.plane, *t_img = img + (size_t)p * 3 * g.plane;
-    const uint32_t plane = (uint32_t)g.plane;
-    for (int i = threadIdx.x; i < CR * CR; i += TPB) {
-        const int lx = i % CR, ly = i / CR;
-        const int X = min(max(gx0 + lx, 0), w - 1), Y = min(max(gy0 + ly, 0), h - 1);
-        const uint32_t o = (uint32_t)Y * g.pitch + (uint32_t)X;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float t = t_img[c * plane + o];
-            A[c][i] = t;
-            M[c][i] = r_img[c * plane + o] * t;
-        }
-    }
-    __syncthreads();
-    const double val = (gx0 >= 0 && gy0 >= 0 && gx0 + CR <= w && gy0 + CR <= h)
-                           ? dssim_compare_stages<true>(A, M, T, r_mu, r_sq, map + (size_t)p * g.plane, g, x0, y0)
-                           : dssim_compare_stages<false>(A, M, T, r_mu, r_sq, map + (size_t)p * g.plane, g, x0, y0);
-    const double t = block_sum(val, s_red);
-    if (threadIdx.x == 0) part[(((size_t)p * n_levels + level) * 2 + 0) * n_blocks + wi.x] = t;
 }
 
 // ---- the tail of every level in two launches (round 3: one avg + one absdev launch per LEVEL were ten of DSSIM's 21 dependent
@@ -528,7 +151,6 @@ void ce_dssim_free(ce_batch *b)
     for (int l = 0; l < CE_DSSIM_SCALES; l++) {
         hipFree(b->ds_rimg[l]); hipFree(b->ds_rmu[l]); hipFree(b->ds_rsq[l]);
         b->ds_rimg[l] = b->ds_rmu[l] = b->ds_rsq[l] = nullptr;
-        ce_free_xcd_list(&b->ds_work[l]);
         hipFree(b->ds_gwork[l].d);
         b->ds_gwork[l] = ce_group_list{};
     }
@@ -576,7 +198,7 @@ static int dssim_allocate(ce_batch *b)
     for (int l = 0; l < n; l++) map_floats += (size_t)b->max_pairs * b->ds[l].plane;
     CE_HIP(ctx, hipMalloc(&b->ds_map, map_floats * sizeof(float)));
     // partial sums per (pair, level): the absdev kernel's blocks, or the compare kernel's strip tiles (>= 2 rows each)
-    b->ds_blocks = std::max(((b->ds[0].w + 63) / 64) * ((b->ds[0].h + 3) / 4), ((b->ds[0].w + CE_DSSIM_STRIP - 1) / CE_DSSIM_STRIP) * ((b->ds[0].h + 1) / 2));
+    b->ds_blocks = std::max(((b->ds[0].w + 63) / 64) * ((b->ds[0].h + AD_ROWS - 1) / AD_ROWS), ((b->ds[0].w + CE_DSSIM_STRIP - 1) / CE_DSSIM_STRIP) * ((b->ds[0].h + 1) / 2));
     CE_HIP(ctx, hipMalloc(&b->ds_part, (size_t)b->max_pairs * CE_DSSIM_SCALES * 2 * b->ds_blocks * sizeof(double)));
     CE_HIP(ctx, hipMalloc(&b->ds_level_scores, (size_t)b->max_pairs * CE_DSSIM_SCALES * sizeof(double)));  // avg, then score
     return CE_OK;
@@ -602,50 +224,19 @@ int ce_launch_dssim(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
     ce_ctx *ctx = b->ctx;
     int rc = dssim_prepare(b);
     if (rc != CE_OK) return rc;
-    const uint32_t n_slots = n_refs_used + n_pairs, mr = b->max_refs;
     // reference handle (ce_ref_*): the references' img / mu / sq pyramid of an earlier launch is still valid
     const bool cached = b->keep_ref_pyramid && b->ds_ref_src == d_refs && b->ds_ref_count >= n_refs_used;
     const uint32_t z0 = cached ? n_refs_used : 0;
     if (!cached) b->ref_builds[1]++;
-    static const bool tile_compare = [] {  // CE_DSSIM_COMPARE=tile: round 2's LDS-tile compare kernel (A/B knob)
-        const char *e = std::getenv("CE_DSSIM_COMPARE");
-        return e && std::string(e) == "tile";
-    }();
-    static const bool tile_create = [] {  // CE_DSSIM_CREATE=tile: round 2's LDS-tile create_image kernel (A/B knob)
-        const char *e = std::getenv("CE_DSSIM_CREATE");
-        return e && std::string(e) == "tile";
-    }();
     ds_geom g{};
     ds_tail tail{};
     size_t map_off = 0;
     for (int l = 0; l < b->ds_levels; l++) {
         const auto &d = b->ds[l];
-        const bool has_next = l + 1 < b->ds_levels;
-        const auto &nd = b->ds[has_next ? l + 1 : l];
-        const lvl_geom lg{d.w, d.h, d.pitch, d.plane}, ng{nd.w, nd.h, nd.pitch, nd.plane};
-        const dim3 tiles((d.w + DT - 1) / DT, (d.h + DT - 1) / DT, 1);
-        // create_image for every used slot (references once per reference)
-        if (!tile_create) {
-            if ((rc = ce_dssim_create_stream(b, l, d_refs, n_refs_used, n_pairs, z0)) != CE_OK) return rc;
-        } else if (l == 0)
-            CE_LAUNCH(ctx, "dssim_create_u8", k_dssim_create<true>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
-                      ctx->d_lut_powf, (const float *)nullptr, b->ds_lin[1], b->ds_img, b->ds_rimg[l], b->ds_rmu[l],
-                      b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
-        else
-            CE_LAUNCH(ctx, "dssim_create", k_dssim_create<false>, dim3(tiles.x, tiles.y, n_slots - z0), dim3(TPB), 0, d_refs, b->d_tests,
-                      ctx->d_lut_powf, (const float *)b->ds_lin[l & 1], b->ds_lin[(l + 1) & 1], b->ds_img,
-                      b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, mr, z0);
-        // compare per pair
+        // create_image for every used slot (references once per reference), then compare per pair: dssim_stream.hip
+        if ((rc = ce_dssim_create_stream(b, l, d_refs, n_refs_used, n_pairs, z0)) != CE_OK) return rc;
         uint32_t n_part = 0;
-        if (tile_compare) {
-            if ((rc = ce_build_xcd_list(b, n_pairs, tiles.x * tiles.y, &b->ds_work[l])) != CE_OK) return rc;
-            CE_LAUNCH(ctx, "dssim_compare", k_dssim_compare, dim3(b->ds_work[l].len), dim3(TPB), 0, (const float *)b->ds_img,
-                      (const float *)b->ds_rimg[l], (const float *)b->ds_rmu[l], (const float *)b->ds_rsq[l], b->d_pair_ref, b->ds_map + map_off,
-                      b->ds_part, lg, (uint32_t)l, (uint32_t)b->ds_levels, b->ds_blocks, (const uint2 *)b->ds_work[l].d, tiles.x);
-            n_part = tiles.x * tiles.y;
-        } else {
-            if ((rc = ce_dssim_compare_stream(b, l, n_pairs, b->ds_map + map_off, &n_part)) != CE_OK) return rc;
-        }
+        if ((rc = ce_dssim_compare_stream(b, l, n_pairs, b->ds_map + map_off, &n_part)) != CE_OK) return rc;
         tail.w[l] = d.w, tail.h[l] = d.h, tail.pitch[l] = d.pitch, tail.plane[l] = d.plane, tail.n_part[l] = n_part;
         tail.gx[l] = (d.w + 63) / 64;
         tail.map_off[l] = map_off;

@@ -354,7 +354,7 @@ __device__ __forceinline__ void dssim_create_strip(const uint8_t *__restrict__ s
 }
 
 // grid (tile groups of CS_WAVES, image slots z0 ..): a block's waves are neighbouring strip tiles of ONE slot
-template <bool FROM_U8, int KIND>
+template <bool FROM_U8>
 __global__ __launch_bounds__(CS_WAVES * 64) void k_dssim_create_stream(const uint8_t *__restrict__ refs, const uint8_t *__restrict__ tests,
                                                                        const float *__restrict__ lut, const float *__restrict__ lin_in,
                                                                        float *__restrict__ lin_out, float *__restrict__ img,
@@ -388,12 +388,12 @@ __global__ __launch_bounds__(CS_WAVES * 64) void k_dssim_create_stream(const uin
         oq[c] = rsq + ((size_t)oslot * 3 + c) * g.plane;
     }
     const bool edge = xs == 0 || xs + (int)out_cols + (is_ref ? CR_HALO_REF : CR_HALO_DIST) >= (int)g.w;
-    if (KIND != 2 && (KIND == 1 || is_ref)) {
+    if (is_ref) {
         if (edge)
             dssim_create_strip<FROM_U8, true, true>(src8, srcf, s_lut, lo, oi, om, oq, g, gn, has_next, xs, y0, y1);
         else
             dssim_create_strip<FROM_U8, true, false>(src8, srcf, s_lut, lo, oi, om, oq, g, gn, has_next, xs, y0, y1);
-    } else if (KIND != 1) {
+    } else {
         if (edge)
             dssim_create_strip<FROM_U8, false, true>(src8, srcf, s_lut, lo, oi, om, oq, g, gn, has_next, xs, y0, y1);
         else
@@ -475,31 +475,13 @@ int ce_dssim_create_stream(ce_batch *b, int l, const uint8_t *d_refs, uint32_t n
     const uint32_t strips_ref = (d.w + 64 - 2 * CR_HALO_REF - 1) / (64 - 2 * CR_HALO_REF), strips = (d.w + CS_OUT - 1) / CS_OUT;
     const uint32_t rows = stream_rows(strips, d.h, n_slots - z0);
     const uint32_t tiles = std::max(z0 < n_refs_used ? strips_ref : 0u, strips) * ((d.h + rows - 1) / rows);
-    static const bool split = [] {  // CE_DSSIM_CREATE=split: references and distorted images in launches of their own (A/B knob)
-        const char *e = std::getenv("CE_DSSIM_CREATE");
-        return e && std::string(e) == "split";
-    }();
-#define CE_CREATE_LAUNCH(NAME, U8, KIND, GRID, Z0)                                                                                        \
-    CE_LAUNCH(ctx, NAME, (k_dssim_create_stream<U8, KIND>), GRID, dim3(CS_WAVES * 64), 0, d_refs, (const uint8_t *)b->d_tests,            \
+#define CE_CREATE_LAUNCH(NAME, U8, GRID, Z0)                                                                                        \
+    CE_LAUNCH(ctx, NAME, (k_dssim_create_stream<U8>), GRID, dim3(CS_WAVES * 64), 0, d_refs, (const uint8_t *)b->d_tests,            \
               (const float *)ctx->d_lut_powf, (const float *)(l == 0 ? nullptr : b->ds_lin[l & 1]), b->ds_lin[(l + 1) & 1], b->ds_img,      \
               b->ds_rimg[l], b->ds_rmu[l], b->ds_rsq[l], lg, ng, has_next ? 1 : 0, b->img_bytes, n_refs_used, b->max_refs, Z0, rows)
-    const uint32_t row_blocks = (d.h + rows - 1) / rows;
-    if (split) {
-        if (z0 < n_refs_used) {
-            const dim3 gr((strips_ref * row_blocks + CS_WAVES - 1) / CS_WAVES, n_refs_used - z0);
-            if (l == 0) CE_CREATE_LAUNCH("dssim_create_u8", true, 1, gr, z0);
-            else CE_CREATE_LAUNCH("dssim_create", false, 1, gr, z0);
-        }
-        if (n_pairs) {
-            const dim3 gd((strips * row_blocks + CS_WAVES - 1) / CS_WAVES, n_pairs);
-            if (l == 0) CE_CREATE_LAUNCH("dssim_create_u8", true, 2, gd, n_refs_used);
-            else CE_CREATE_LAUNCH("dssim_create", false, 2, gd, n_refs_used);
-        }
-        return CE_OK;
-    }
     const dim3 grid((tiles + CS_WAVES - 1) / CS_WAVES, n_slots - z0);
-    if (l == 0) CE_CREATE_LAUNCH("dssim_create_u8", true, 0, grid, z0);
-    else CE_CREATE_LAUNCH("dssim_create", false, 0, grid, z0);
+    if (l == 0) CE_CREATE_LAUNCH("dssim_create_u8", true, grid, z0);
+    else CE_CREATE_LAUNCH("dssim_create", false, grid, z0);
 #undef CE_CREATE_LAUNCH
     return CE_OK;
 }
