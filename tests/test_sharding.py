@@ -111,3 +111,42 @@ def test_two_rank_gloo_shard_and_gather():
     want = [(k, O.psnr(refs[i], tt, 48, 40), O.sse(refs[i], tt)) for k, (i, tt) in enumerate(items)]
     assert merged == want  # complete, ordered, bit-identical to the single-process run
     assert 0 < n0 < len(items)  # rank 0 really owned only part of the grid
+
+
+def test_bench_workload_shards_tile_the_global_sweep():
+    """bench.py's default workload for N ranks: ONE global grid (N Kodak sets + N CID22-shaped sets) partitioned by reference.
+    The ranks' shards must be disjoint, cover every cell exactly once, carry equal loads, and every cell must be
+    reproducible from its key alone (rank 0 recomputes a foreign cell that way)."""
+    import argparse
+    import importlib
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    import codec_eval_amd as ce
+
+    wl = importlib.import_module("codec-eval_amd.workloads")
+    sh = importlib.import_module("codec-eval_amd.sharding")
+    args = argparse.Namespace(quick=True, refs=0, kodak_only=False, one_shape=False)
+    world = 2
+    shards = [bench.Workload(0, args, r, world, ce, wl, sh) for r in range(world)]
+    keys, loads = [], []
+    for wk in shards:
+        ks = [wk.key(group, c, pid) for g, c, group in wk.launches for pid in g.pair_ids]
+        keys += ks
+        loads.append(wk.mp_per_step)
+        assert wk.scaling == "weak" and wk.mode == "reference" and wk.n_eval_metrics == 3
+        assert all(len(g.references) <= bench.CID_CHUNK_REFS for g, _, group in wk.launches if group == "cid")
+    n = world * (6 * 3 + 8 * 8)
+    assert len(keys) == len(set(keys)) == n and abs(loads[0] - loads[1]) < 1e-9
+    # a cell regenerated from its key is the cell the owning rank scored
+    g, c, group = shards[1].launches[0]
+    key = shards[1].key(group, c, g.pair_ids[3])
+    ref, test, w, h, cfg = shards[0].regenerate(key, wl, world)
+    ri, t = g.pairs[3]
+    assert (w, h) == (g.width, g.height) and np.array_equal(ref, g.references[ri]) and np.array_equal(test, t) and cfg.mask == c.mask
+    # the fixed-grid (strong scaling) leg: the same 16 references split 8 / 8
+    strong = [bench.Workload(4, args, r, world, ce, wl, sh, as_strong=True) for r in range(world)]
+    assert [s.pairs_per_step for s in strong] == [64, 64] and strong[0].scaling == "strong"
+    assert not {pid[0] for g, _, _ in strong[0].launches for pid in g.pair_ids} & {pid[0] for g, _, _ in strong[1].launches for pid in g.pair_ids}
