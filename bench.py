@@ -209,6 +209,16 @@ class Workload:
         self.pairs_per_step = sum(len(g.pairs) for g, _, _ in self.launches)
         self.mp_per_step = sum(g.megapixels for g, _, _ in self.launches)
 
+    def subset(self, launches):
+        """The same workload restricted to some of its batches (the Kodak grid alone, for `kodak_only`)."""
+        import copy
+
+        sub = copy.copy(self)
+        sub.launches = list(launches)
+        sub.pairs_per_step = sum(len(g.pairs) for g, _, _ in sub.launches)
+        sub.mp_per_step = sum(g.megapixels for g, _, _ in sub.launches)
+        return sub
+
     def key(self, group, c, pid):
         return (group, pid[0], pid[1] + (2 if c.xyb_roundtrip and self.cfg_id == 5 else 0), pid[2])
 
@@ -575,10 +585,7 @@ def main():
     # ---- Kodak grid alone: rounds 1-2's headline, for continuity (config 0, N = 1) ------------------------------------------------------
     kodak_launches = [l for l in launches_main if l[2] == "kodak"]
     if args.config == 0 and world == 1 and kodak_launches and len(kodak_launches) < len(launches_main) and not args.no_kodak_only:
-        kw = Workload.__new__(Workload)
-        kw.__dict__.update(wkl.__dict__)
-        kw.launches = kodak_launches
-        kw.mp_per_step = sum(g.megapixels for g, _, _ in kodak_launches)
+        kw = wkl.subset(kodak_launches)
         kres = Resident(ce, kw, local_rank, 2)
         n = max(args.steps, 20)
         _, _, dt = timed(kres, n, max(args.warmup, 3), 2 * len(kodak_launches) - 1)
