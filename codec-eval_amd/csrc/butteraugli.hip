@@ -1194,6 +1194,12 @@ void ce_butteraugli_free(ce_batch *b)
         b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
     }
     for (auto &p : b->ba_s) hipFree(p), p = nullptr;
+    for (auto &p : b->ba_s_half) hipFree(p), p = nullptr;
+    if (b->ba_half_stream) hipStreamSynchronize(b->ba_half_stream), hipStreamDestroy(b->ba_half_stream);
+    if (b->ev_ba_fork) hipEventDestroy(b->ev_ba_fork);
+    if (b->ev_ba_join) hipEventDestroy(b->ev_ba_join);
+    b->ba_half_stream = nullptr;
+    b->ev_ba_fork = b->ev_ba_join = nullptr;
     hipFree(b->ba_blk_max);
     hipFree(b->ba_blk_sums);
     hipFree(b->ba_pnorm);
@@ -1250,6 +1256,15 @@ static int ba_prepare(ce_batch *b)
     return CE_OK;
 }
 
+static bool ba_one_stream()  // CE_BA_LEVEL_STREAMS=1: both resolution levels on one stream whatever the batch size (A/B knob)
+{
+    static const bool v = [] {
+        const char *e = std::getenv("CE_BA_LEVEL_STREAMS");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, uint32_t n_pairs, float intensity_target)
 {
     ce_ctx *ctx = b->ctx;
@@ -1275,23 +1290,43 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     const malta_params mMfX = make_malta(8246.75321353, 8246.75321353, 1009002.70582, true);
 
     // half resolution first: the full-resolution level's Malta kernel folds that diffmap into its own values and reduces
-    // them to the score partials
+    // them to the score partials.
+    // A small batch (the one-pair-per-call regime) is a chain of 16 dependent launches of a few workgroups each; the two
+    // resolution levels are independent until the full-resolution Malta kernel, so the half-resolution chain runs on a stream
+    // of its own (with its own scratch planes) beside the full-resolution one: two cross-stream events instead of seven
+    // launches on the critical path (profiles/r03_experiments.md section 14).
+    const bool two_streams = b->ba_levels == 2 && !ctx->prof_serial && (double)n_pairs * b->w * b->h <= 4e6 && !ba_one_stream();
+    hipStream_t s_main = CE_STREAM(ctx), s_half = s_main;
+    if (two_streams) {
+        if (!b->ba_half_stream) {
+            CE_HIP(ctx, hipStreamCreateWithFlags(&b->ba_half_stream, hipStreamNonBlocking));
+            CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_ba_fork, hipEventDisableTiming));
+            CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_ba_join, hipEventDisableTiming));
+            const size_t slots = (size_t)b->max_refs + b->max_pairs;
+            for (auto &p : b->ba_s_half) CE_HIP(ctx, hipMalloc(&p, slots * 3 * b->ba[1].plane * sizeof(float)));
+        }
+        s_half = b->ba_half_stream;
+        CE_HIP(ctx, hipEventRecord(b->ev_ba_fork, s_main));
+        CE_HIP(ctx, hipStreamWaitEvent(s_half, b->ev_ba_fork, 0));
+    }
     uint32_t final_tiles = 0;
     for (int l = b->ba_levels - 1; l >= 0; l--) {
         const auto &d = b->ba[l];
         const geom g{d.w, d.h, d.pitch, d.plane};
         const dim3 gx((d.w + 63) / 64, (d.h + 3) / 4, 1);
         auto G = [&](uint32_t z) { return dim3(gx.x, gx.y, z); };
-        float *psy = b->ba_psy[l], *sA = b->ba_s[0], *sC = b->ba_s[2];
+        hipStream_t st = l == 1 ? s_half : s_main;
+        float *const *scr = (two_streams && l == 1) ? b->ba_s_half : b->ba_s;
+        float *psy = b->ba_psy[l], *sA = scr[0], *sC = scr[2];
         // ---- per image slot: PsychoImage ----
         const plane_sel s3{3, 0, 3};
         const dim3 ft((d.w + FT - 1) / FT, (d.h + FT - 1) / FT, nz);
         if (l == 0) {
-            CE_LAUNCH(ctx, "ba_front_u8", k_ba_front<false>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, g, sC, g, w0, w1, w2,
+            CE_LAUNCH_ON(ctx, st, "ba_front_u8", k_ba_front<false>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2, g, sC, g, w0, w1, w2,
                       intensity_target, b->img_bytes, n_refs_used, mr, z0);
         } else {
             const auto &pd = b->ba[0];
-            CE_LAUNCH(ctx, "ba_front_half", k_ba_front<true>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
+            CE_LAUNCH_ON(ctx, st, "ba_front_half", k_ba_front<true>, ft, dim3(TPB), 0, d_refs, b->d_tests, ctx->d_lut_ssim2,
                       geom{pd.w, pd.h, pd.pitch, pd.plane}, sC, g, w0, w1, w2, intensity_target, b->img_bytes, n_refs_used, mr, z0);
         }
         // LF = blur(xyb, 7.156) -> psy[LF0..2]
@@ -1303,9 +1338,9 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
             }
             const dim3 gh3((g.w + 255) / 256, (g.h + 8 * BH_TILES - 1) / (8 * BH_TILES), nz * 3);
             const dim3 gvs((g.w + 63) / 64, (g.h + 63) / 64, nz);
-            float *sB = b->ba_s[1];
+            float *sB = scr[1];
             // LF: row pass sC -> sA, column pass + split: LF -> psy, raw MF -> sB
-            CE_LAUNCH(ctx, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
+            CE_LAUNCH_ON(ctx, st, "ba_blur_h33", k_ba_blur_h<33>, gh3, dim3(TPB), 0, (const float *)sC, sA, g, s3, s3, kLf, inv_weight_sum(kLf),
                       n_refs_used, mr, 1, z0);
             // rows per block of the column / fused stages: 32 (default; 26 / 21 KB of LDS and ~100 / 56 registers: five blocks per CU)
             // or 64 (CE_HV_ROWS=64: smaller halo, 45 / 38 KB, three or four blocks).  Measured (profiles/r02_experiments.md
@@ -1317,24 +1352,24 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
             }();
             const dim3 gvs32((g.w + 63) / 64, (g.h + 31) / 32, nz);
             if (hv_rows == 32)
-                CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
+                CE_LAUNCH_ON(ctx, st, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
                           (const float *)sC, psy, g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
             else
-            CE_LAUNCH(ctx, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy,
+            CE_LAUNCH_ON(ctx, st, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)sC, psy,
                       g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
             // MF: row + column pass of raw MF (sB) + split: MF -> psy, raw HF -> sA (its old contents are dead)
             if (hv_rows == 32)
-                CE_LAUNCH(ctx, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sB,
+                CE_LAUNCH_ON(ctx, st, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sB,
                           (const float *)nullptr, psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr, sA);
             else
-            CE_LAUNCH(ctx, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true>), gvs, dim3(TPB), 0, (const float *)sB, (const float *)nullptr,
+            CE_LAUNCH_ON(ctx, st, "ba_blur_hv_mf", (k_ba_blur_v_split<15, EPI_MF, true>), gvs, dim3(TPB), 0, (const float *)sB, (const float *)nullptr,
                       psy, g, kHf, inv_weight_sum(kHf), n_refs_used, mr, z0, (float *)nullptr, sA);
             // HF: row + column pass of raw HF (sA) + split: HF, UHF -> psy, the mask input -> sB (raw MF is dead)
             if (hv_rows == 32)
-                CE_LAUNCH(ctx, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
+                CE_LAUNCH_ON(ctx, st, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
                           (const float *)nullptr, psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, sB, (float *)nullptr);
             else
-            CE_LAUNCH(ctx, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
+            CE_LAUNCH_ON(ctx, st, "ba_blur_hv_hf", (k_ba_blur_v_split<7, EPI_HF, true>), gvs, dim3(TPB), 0, (const float *)sA, (const float *)nullptr,
                       psy, g, kUhf, inv_weight_sum(kUhf), n_refs_used, mr, z0, sB, (float *)nullptr);
         }
 
@@ -1348,11 +1383,11 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                 return CE_ERR_BACKEND;
             }
             const dim3 gm((g.w + 63) / 64, (g.h + 31) / 32, nz);
-            CE_LAUNCH(ctx, "ba_blur_hv_mask", (k_ba_blur_v_split<13, EPI_MASK, true, 32>), gm, dim3(TPB), 0, (const float *)b->ba_s[1],
+            CE_LAUNCH_ON(ctx, st, "ba_blur_hv_mask", (k_ba_blur_v_split<13, EPI_MASK, true, 32>), gm, dim3(TPB), 0, (const float *)scr[1],
                       (const float *)nullptr, psy, g, kMask, inv_weight_sum(kMask), n_refs_used, mr, z0, (float *)nullptr, b->ba_mask[l]);
         }
         if (!cached)
-            CE_LAUNCH(ctx, "ba_mask_vals", k_ba_mask_vals, G(n_refs_used), dim3(TPB), 0, (const float *)b->ba_mask[l], b->ba_mask_vals[l], g);
+            CE_LAUNCH_ON(ctx, st, "ba_mask_vals", k_ba_mask_vals, G(n_refs_used), dim3(TPB), 0, (const float *)b->ba_mask[l], b->ba_mask_vals[l], g);
 
         // ---- per pair: Malta + L2 terms + CombineChannelsToDiffmap -> the level's diffmap ----
         // tile height: 64 rows / 512 threads for images that fill the chip with such tiles, else 32 rows / 256 threads
@@ -1372,12 +1407,13 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
         const auto &ds = b->ba[has_sub ? 1 : 0];
         const geom gsub{ds.w, ds.h, ds.pitch, ds.plane};
 #define CE_MALTA_LAUNCH(ROWS, THREADS, FINAL)                                                                                      \
-    CE_LAUNCH(ctx, "ba_malta_l2", (k_ba_malta_l2_xy<ROWS, THREADS, FINAL>), dim3(b->ba_work[l].len), dim3(THREADS), 0, psy, b->d_pair_ref, \
+    CE_LAUNCH_ON(ctx, st, "ba_malta_l2", (k_ba_malta_l2_xy<ROWS, THREADS, FINAL>), dim3(b->ba_work[l].len), dim3(THREADS), 0, psy, b->d_pair_ref, \
               (const float *)b->ba_mask[l], (const float *)b->ba_mask_vals[l], FINAL ? (float *)nullptr : b->ba_diff[1], g, mr, mb,       \
               (const uint2 *)b->ba_work[l].d, tiles_x, FINAL ? (const float *)b->ba_diff[1] : (const float *)nullptr, gsub,               \
               has_sub ? 1 : 0, b->ba_blk_max, b->ba_blk_sums, b->ba_blocks)
         if (l == 0) {
             final_tiles = tiles_x * tiles_y;
+            if (two_streams) CE_HIP(ctx, hipStreamWaitEvent(s_main, b->ev_ba_join, 0));  // the half-resolution diffmap
             if (malta_rows == 64)
                 CE_MALTA_LAUNCH(64, 512, true);
             else
@@ -1387,6 +1423,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                 CE_MALTA_LAUNCH(64, 512, false);
             else
                 CE_MALTA_LAUNCH(32, 256, false);
+            if (two_streams) CE_HIP(ctx, hipEventRecord(b->ev_ba_join, s_half));
         }
 #undef CE_MALTA_LAUNCH
     }

@@ -190,6 +190,11 @@ struct ce_batch {
     float *ba_diff[2] = {};   // [pair][plane_1]      the half-resolution diffmap ([1]; the full-resolution one is reduced in registers)
     float *ba_mask[2] = {};   // [slot][plane_l]      blurred mask input (DiffPrecompute of HF + UHF, sigma 2.7)
     float *ba_s[3] = {};      // per-slot scratch, 3 planes each
+    // a small batch runs its half-resolution chain on a stream of its own, beside the full-resolution one, with its own
+    // scratch (butteraugli.hip: ce_launch_butteraugli); made on first use
+    float *ba_s_half[3] = {};
+    hipStream_t ba_half_stream = nullptr;
+    hipEvent_t ev_ba_fork = nullptr, ev_ba_join = nullptr;
     float *ba_mask_vals[2] = {};  // [ref][2][plane_l]    maskval / dc_maskval of the references (FuzzyErosion + mask curves)
     float *ba_blk_max = nullptr;
     double *ba_blk_sums = nullptr;
