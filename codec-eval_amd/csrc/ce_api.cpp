@@ -159,7 +159,7 @@ thread_local hipStream_t ce_tls_stream = nullptr;  // ce_internal.h: CE_STREAM
 
 extern "C" {
 
-const char *ce_version(void) { return "codec-eval_amd 0.2.0 (gfx950)"; }
+const char *ce_version(void) { return "codec-eval_amd 0.3.0 (gfx950)"; }
 
 int ce_device_count(void)
 {
