@@ -499,11 +499,14 @@ def main():
             kernels_tbl[k] = row
         name = dominant or (max((k for k in in_region if k in alg), key=lambda k: in_region[k][1], default=None))
         if name is not None:
-            px0 = sum(len(g.pairs) * g.width * g.height for g, _, _ in wkl.launches)
             lps = (solo[name][0] / solo_steps) if name in solo else (in_region[name][0] / args.steps)
             rec = traffic_tbl.get(name)
-            traffic = rec["bytes_per_scale0_pixel"] * px0 / lps if isinstance(rec, dict) else None  # HBM bytes per launch, PMC counters
             bytes_per_launch = alg[name] / lps
+            # HBM bytes per launch from the PMC counters: the kernel's measured traffic-over-algorithmic ratio (profiled on the
+            # Kodak bucket) applied to THIS workload's algorithmic bytes per launch - the per-pixel figure itself depends on how
+            # many distorted images share a reference (3 in the profiled bucket, 8 in the CID22 chunks)
+            traffic = (bytes_per_launch * rec["traffic_over_algorithmic"]
+                       if isinstance(rec, dict) and rec.get("traffic_over_algorithmic") else None)
             sq = sq_tbl.get(name)
             valu = float(sq["valu_util"]) if sq else None
             # the roof that binds the kernel: the vector ALUs when the SQ counters say they are busy most of the time
