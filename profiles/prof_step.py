@@ -7,6 +7,7 @@ config 2: the same grid, SSIMULACRA2 only
 config 3: 2 pairs of 3840x2160, Butteraugli
 config 4: 16 references 512x512 x 8 qualities, SSIMULACRA2 + DSSIM
 config 5: 4 references 512x512 x 25 qualities x {4:4:4, 4:2:0}, all four metrics, XYB roundtrip on
+config 6: 16 references 512x512 x 8 qualities, SSIMULACRA2 + DSSIM + Butteraugli  (the shape of the default sweep's CID22 chunks)
 
 Every run starts with the known-byte-count calibration streams (ce_debug_calibrate_traffic, 256 MiB): make_traffic.py
 derives FETCH_SIZE's / WRITE_SIZE's correction factor per access width from them, in the same pass.
@@ -51,6 +52,9 @@ elif config == 3:
 elif config == 4:
     w, h, (refs, pairs) = 512, 512, cheap_grid(512, 512, 16, 8)
     cfg = ce.MetricConfig(ssimulacra2=True, dssim=True)
+elif config == 6:
+    w, h, (refs, pairs) = 512, 512, cheap_grid(512, 512, 16, 8)
+    cfg = ce.MetricConfig.perceptual()
 else:
     w, h, (refs, pairs) = 512, 512, cheap_grid(512, 512, 4, 50)
     cfg = ce.MetricConfig.all().with_xyb_roundtrip()
