@@ -379,8 +379,11 @@ void ce_batch_destroy(ce_batch *b)
     hipStreamSynchronize(b->ctx->stream);
     leave_flight(b);
     if (b->up_stream) hipStreamSynchronize(b->up_stream), hipStreamDestroy(b->up_stream);
-    if (b->h_wide) hipHostFree(b->h_wide);
-    hipFree(b->d_wide);
+    for (int k = 0; k < 2; k++) {
+        if (b->h_wide[k]) hipHostFree(b->h_wide[k]);
+        hipFree(b->d_wide[k]);
+        if (b->ev_wide[k]) hipEventDestroy(b->ev_wide[k]);
+    }
     if (b->ev_up) hipEventDestroy(b->ev_up);
     if (b->ev_run) hipEventDestroy(b->ev_run);
     if (b->ev_fork) hipEventDestroy(b->ev_fork);
@@ -577,19 +580,24 @@ static int upload_fmt(ce_batch *b, uint8_t *dst, const void *pixels, size_t len,
                                                 std::to_string(len));
     if (format == CE_PIXEL_RGB8) return upload(b, dst, static_cast<const uint8_t *>(pixels), false);
     CE_HIP(ctx, hipSetDevice(ctx->device));  // the staging allocations and the ingest launch below go to the context's device
-    if (!b->h_wide) {
-        CE_HIP(ctx, hipHostMalloc(&b->h_wide, n_px * 8, hipHostMallocDefault));
-        CE_HIP(ctx, hipMalloc(&b->d_wide, n_px * 8));
+    const int k = b->next_wide;
+    b->next_wide ^= 1;
+    if (!b->h_wide[k]) {
+        CE_HIP(ctx, hipHostMalloc((void **)&b->h_wide[k], n_px * 8, hipHostMallocDefault));
+        CE_HIP(ctx, hipMalloc((void **)&b->d_wide[k], n_px * 8));
+        CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_wide[k], hipEventDisableTiming));
     }
     if (b->run_pending) {
         CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
         b->run_pending = false;
     }
-    CE_HIP(ctx, hipStreamSynchronize(b->up_stream));  // the single wide staging image is free again
-    std::memcpy(b->h_wide, pixels, len);
-    CE_HIP(ctx, hipMemcpyAsync(b->d_wide, b->h_wide, len, hipMemcpyHostToDevice, b->up_stream));
-    int rc = ce_launch_ingest(ctx, b->up_stream, format, b->d_wide, dst, n_px);
+    if (b->wide_busy[k]) CE_HIP(ctx, hipEventSynchronize(b->ev_wide[k]));  // this staging pair's previous image has been converted
+    std::memcpy(b->h_wide[k], pixels, len);
+    CE_HIP(ctx, hipMemcpyAsync(b->d_wide[k], b->h_wide[k], len, hipMemcpyHostToDevice, b->up_stream));
+    int rc = ce_launch_ingest(ctx, b->up_stream, format, b->d_wide[k], dst, n_px);
     if (rc != CE_OK) return rc;
+    CE_HIP(ctx, hipEventRecord(b->ev_wide[k], b->up_stream));
+    b->wide_busy[k] = true;
     b->uploads_pending = true;
     return CE_OK;
 }

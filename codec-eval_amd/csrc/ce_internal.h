@@ -127,7 +127,12 @@ struct ce_batch {
     bool uploads_pending = false, run_pending = false;
     bool counted_in_flight = false;  // this batch is in the device's launched-and-not-collected count (ce_api.cpp: g_in_flight)
     // wide ingest (RGBA8 / 16-bit sources): one pinned + one device staging image of 8 B/px, made on first use
-    uint8_t *h_wide = nullptr, *d_wide = nullptr;
+    // (two of each: while image k's copy and conversion are in flight the host fills the other pair, so a sweep of wide
+    // decoded images does not synchronise the upload stream per image)
+    uint8_t *h_wide[2] = {}, *d_wide[2] = {};
+    hipEvent_t ev_wide[2] = {};
+    bool wide_busy[2] = {};
+    int next_wide = 0;
 
     // SSIMULACRA2 working set.  Image slots: [0, max_refs) references, then tests.
     int n_scales = 0;
