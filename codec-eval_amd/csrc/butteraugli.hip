@@ -1195,7 +1195,7 @@ void ce_butteraugli_free(ce_batch *b)
     }
     for (auto &p : b->ba_s) hipFree(p), p = nullptr;
     for (auto &p : b->ba_s_half) hipFree(p), p = nullptr;
-    if (b->ba_half_stream) hipStreamSynchronize(b->ba_half_stream), hipStreamDestroy(b->ba_half_stream);
+    if (b->ba_half_stream) hipStreamSynchronize(b->ba_half_stream);  // the context's stream: drained, not destroyed
     if (b->ev_ba_fork) hipEventDestroy(b->ev_ba_fork);
     if (b->ev_ba_join) hipEventDestroy(b->ev_ba_join);
     b->ba_half_stream = nullptr;
@@ -1299,7 +1299,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
     hipStream_t s_main = CE_STREAM(ctx), s_half = s_main;
     if (two_streams) {
         if (!b->ba_half_stream) {
-            CE_HIP(ctx, hipStreamCreateWithFlags(&b->ba_half_stream, hipStreamNonBlocking));
+            if (!(b->ba_half_stream = ce_ctx_aux_stream(ctx, ce_ctx::AUX_BA_HALF))) return CE_ERR_BACKEND;
             CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_ba_fork, hipEventDisableTiming));
             CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_ba_join, hipEventDisableTiming));
             const size_t slots = (size_t)b->max_refs + b->max_pairs;

@@ -157,6 +157,19 @@ void ce_free_xcd_list(ce_xcd_list *L)
 
 thread_local hipStream_t ce_tls_stream = nullptr;  // ce_internal.h: CE_STREAM
 
+hipStream_t ce_ctx_aux_stream(ce_ctx *ctx, int which)
+{
+    if (which < 0 || which >= ce_ctx::AUX_COUNT) return nullptr;
+    if (!ctx->aux_stream[which]) {
+        const hipError_t e = hipStreamCreateWithFlags(&ctx->aux_stream[which], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            ctx->aux_stream[which] = nullptr;
+            ctx->err = std::string("hipStreamCreateWithFlags (auxiliary stream): ") + hipGetErrorString(e);
+        }
+    }
+    return ctx->aux_stream[which];
+}
+
 extern "C" {
 
 const char *ce_version(void) { return "codec-eval_amd 0.3.0 (gfx950)"; }
@@ -282,9 +295,12 @@ void ce_ctx_destroy(ce_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     delete ctx->helpers;
     ctx->helpers = nullptr;
+
     prof_drain(ctx);
     for (auto &kv : ctx->shape_pool) ce_batch_destroy(kv.second);
     ctx->shape_pool.clear();
+    for (auto &st : ctx->aux_stream)  // after the last batch that may still drain them
+        if (st) hipStreamSynchronize(st), hipStreamDestroy(st), st = nullptr;
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
@@ -398,7 +414,7 @@ void ce_batch_destroy(ce_batch *b)
         if (b->ev_stage[k]) hipEventDestroy(b->ev_stage[k]);
     }
     for (int l = 0; l < 3; l++) {
-        if (b->metric_stream[l]) hipStreamSynchronize(b->metric_stream[l]), hipStreamDestroy(b->metric_stream[l]);
+        if (b->metric_stream[l]) hipStreamSynchronize(b->metric_stream[l]);  // the context's stream: drained, not destroyed
         if (b->ev_join[l]) hipEventDestroy(b->ev_join[l]);
     }
     ce_ssim2_free(b);
@@ -814,7 +830,7 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
     unsigned joined = 0;
     auto prepare_fork = [&](int k) -> int {  // the chain's stream exists and waits for the fork point
         if (!b->metric_stream[k]) {
-            CE_HIP(ctx, hipStreamCreateWithFlags(&b->metric_stream[k], hipStreamNonBlocking));
+            if (!(b->metric_stream[k] = ce_ctx_aux_stream(ctx, ce_ctx::AUX_METRIC0 + k))) return CE_ERR_BACKEND;
             CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_join[k], hipEventDisableTiming));
         }
         CE_HIP(ctx, hipStreamWaitEvent(b->metric_stream[k], b->ev_fork, 0));

@@ -82,6 +82,15 @@ struct ce_ctx {
     uint8_t *leaf_d_in = nullptr, *leaf_d_out = nullptr, *leaf_h = nullptr;
     size_t leaf_in_cap = 0, leaf_out_cap = 0, leaf_h_cap = 0;
 
+    // Auxiliary streams of the context, shared by all its batches (made on first use, destroyed with the context): the
+    // three metric chains of a forked batch, SSIMULACRA2's level-0 passes (+ the chunking experiment's second one),
+    // Butteraugli's half-resolution chain.  Rounds 1-2 made them per BATCH: a context with a scratch batch and a reference
+    // handle then held 13 streams, HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues in creation order, and two
+    // chains of one call could land on one queue - the same call took 0.45 or 0.8 ms depending on what had been created
+    // before it (profiles/r03_experiments.md section 15).
+    enum { AUX_METRIC0 = 0, AUX_SSIM2_L0 = 3, AUX_SSIM2_L0B = 4, AUX_BA_HALF = 5, AUX_COUNT = 6 };
+    hipStream_t aux_stream[AUX_COUNT] = {};
+
     // two parked host threads that enqueue the other metric chains of a forked batch (ce_api.cpp: ce_fork_helpers); made on
     // the first forked launch, joined by ce_ctx_destroy
     struct ce_fork_helpers *helpers = nullptr;
@@ -223,6 +232,9 @@ struct ce_batch {
             return CE_ERR_BACKEND;                                                                 \
         }                                                                                          \
     } while (0)
+
+// the context's auxiliary stream `which` (ce_ctx::AUX_*), made on first use; nullptr + ctx->err on failure (ce_api.cpp)
+hipStream_t ce_ctx_aux_stream(ce_ctx *ctx, int which);
 
 // profiling hooks around a launch (ce_api.cpp)
 int ce_prof_begin(ce_ctx *ctx, const char *name, hipStream_t stream);

@@ -719,7 +719,7 @@ void ce_ssim2_free(ce_batch *b)
         hipFree(b->d_xyb[s]);
         hipFree(b->d_hbuf[s]);
         b->d_lin[s] = b->d_xyb[s] = b->d_hbuf[s] = nullptr;
-        if (b->lvl_stream[s]) hipStreamSynchronize(b->lvl_stream[s]), hipStreamDestroy(b->lvl_stream[s]);
+        if (b->lvl_stream[s]) hipStreamSynchronize(b->lvl_stream[s]);  // the context's stream: drained, not destroyed
         if (b->ev_prep[s]) hipEventDestroy(b->ev_prep[s]);
         if (b->ev_done[s]) hipEventDestroy(b->ev_done[s]);
         b->lvl_stream[s] = nullptr;
@@ -742,7 +742,7 @@ static int ssim2_allocate(ce_batch *b)
     for (int s = 0; s < ns; s++) {
         CE_HIP(ctx, hipMalloc(&b->d_xyb[s], slots * 3 * b->sd[s].plane * sizeof(float)));
         CE_HIP(ctx, hipMalloc(&b->d_hbuf[s], (size_t)b->max_pairs * 3 * CE_SSIM2_STREAMS * b->sd[s].plane * sizeof(float)));
-        if (s == 0) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[0], hipStreamNonBlocking));  // level 0's passes; the other levels follow the front end
+        if (s == 0 && !(b->lvl_stream[0] = ce_ctx_aux_stream(ctx, ce_ctx::AUX_SSIM2_L0))) return CE_ERR_BACKEND;  // level 0's passes; the other levels follow the front end
         CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_prep[s], hipEventDisableTiming));
         CE_HIP(ctx, hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
     }
@@ -945,7 +945,7 @@ int ce_launch_ssim2(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_used, ui
             if (rc != CE_OK) return rc;
             if (ssim2_l0_chunk() && b->work_chunks_h.size() > 1 && s0 != CE_STREAM(ctx) && b->ev_done[2]) {
                 // experiment: segment by segment on two alternating streams (row pass, then column pass of the same segment)
-                if (!b->lvl_stream[1]) CE_HIP(ctx, hipStreamCreateWithFlags(&b->lvl_stream[1], hipStreamNonBlocking));
+                if (!b->lvl_stream[1] && !(b->lvl_stream[1] = ce_ctx_aux_stream(ctx, ce_ctx::AUX_SSIM2_L0B))) return CE_ERR_BACKEND;
                 CE_HIP(ctx, hipStreamWaitEvent(b->lvl_stream[1], b->ev_prep[0], 0));
                 for (size_t ck = 0; ck < b->work_chunks_h.size(); ck++) {
                     hipStream_t sc = (ck & 1) ? b->lvl_stream[1] : s0;
