@@ -602,22 +602,23 @@ def main():
                       "workload": "BASELINE configs[1] grid alone (72 pairs: Kodak-24 x q75/85/95), the three metrics: BENCH_r01 / r02's headline"}
         kres.close()
 
-    # ---- end to end: page-locked host buffers in, scores out (uploads inside the timing; Kodak part of the grid) ------------------------
+    # ---- end to end: page-locked host buffers in, scores out (uploads inside the timing; the whole workload in one ce_eval_batch call per config)
     if not args.no_end_to_end and world == 1 and rank == 0:
-        e2e_l = kodak_launches or launches_main[:1]
-        items, keep = [], []
+        e2e_l = launches_main
+        n_bytes = sum((len(g.references) + len(g.pairs)) * g.width * g.height * 3 for g, _, _ in e2e_l)
+        slab = torch.empty(n_bytes, dtype=torch.uint8).pin_memory()  # one page-locked allocation, the images are views into it
+        host, off, items = slab.numpy(), 0, []
+
+        def place(a):
+            nonlocal off
+            v = host[off:off + a.size]
+            v[:] = a.reshape(-1)
+            off += a.size
+            return v
         for g, c, _ in e2e_l:
-            refs_p = []
-            for r in g.references:
-                t = torch.empty(r.size, dtype=torch.uint8).pin_memory()
-                t.numpy()[:] = r.reshape(-1)
-                refs_p.append(t)
+            refs_p = [place(r) for r in g.references]
             for ri, tt in g.pairs:
-                t = torch.empty(tt.size, dtype=torch.uint8).pin_memory()
-                t.numpy()[:] = tt.reshape(-1)
-                keep.append(t)
-                items.append((c, (refs_p[ri].numpy(), t.numpy(), g.width, g.height)))
-            keep.extend(refs_p)
+                items.append((c, (refs_p[ri], place(tt), g.width, g.height)))
         by_cfg = {}
         for c, it in items:
             by_cfg.setdefault((c.mask, c.flags), (c, []))[1].append(it)
@@ -626,19 +627,20 @@ def main():
             def e2e_step():
                 for c, its in by_cfg.values():
                     cx.eval_batch(its, c)
-            e2e_step()
-            n = max(2, min(args.steps, 10))
+            for _ in range(2):  # the first call allocates the pooled batches, the second settles their sizes
+                e2e_step()
+            n = max(3, min(args.steps, 10))
             t1 = time.perf_counter()
             for _ in range(n):
                 e2e_step()
             dt = time.perf_counter() - t1
         end_to_end = {"value": round(mp * wkl.n_eval_metrics * n / dt, 2), "unit": "MP/s", "ms_per_step": round(dt / n * 1e3, 3), "steps": n,
-                      "grid": "the Kodak part of the workload" if kodak_launches else "the first batch of the workload",
-                      "route": "ce_eval_batch: page-locked host RGB8 in -> H2D on the upload stream (chunked, overlapped with the "
-                               "kernels of the previous chunk) -> kernels -> scores on the host; 6 B/px over PCIe per pair "
-                               "(3 B/px for the pairs that share an already uploaded reference)",
-                      "h2d_megabytes_per_step": round(sum((len(g.references) + len(g.pairs)) * g.width * g.height * 3 for g, _, _ in e2e_l) / 1e6, 1)}
-        del keep
+                      "grid": "the whole workload, one ce_eval_batch call",
+                      "route": "ce_eval_batch: page-locked host RGB8 in -> H2D on the upload streams (chunks that start small and "
+                               "double, each overlapped with the kernels of the chunk before) -> kernels -> scores on the host; "
+                               "3 B/px over PCIe per distorted image + 3 B/px per reference",
+                      "h2d_megabytes_per_step": round(n_bytes / 1e6, 1)}
+        del items, host, slab
 
     # ---- per call: the reference's one GPU plug point is ONE blocking call per encode (crates/codec-iter/src/gpu.rs:83-109) -------------
     if not args.no_per_call and world == 1 and rank == 0:

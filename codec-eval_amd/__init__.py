@@ -415,11 +415,17 @@ class Context:
         test_tables: optional per-pair ColorTable (or None) applied to the distorted image on the device."""
         n = len(pairs)
         descs = (CePairDesc * n)()
-        keep = []
+        keep = {}  # id(buffer) -> (flat view, address, length): a reference shared by many pairs is looked at once
+
+        def addr(a):
+            e = keep.get(id(a))
+            if e is None:
+                v = _buf(a)
+                e = keep[id(a)] = (v, v.__array_interface__["data"][0], v.size, a)
+            return e
         for i, (ref, test, w, h) in enumerate(pairs):
-            r, t = _buf(ref), _buf(test)
-            keep.append((r, t))
-            descs[i] = CePairDesc(r.ctypes.data, r.size, t.ctypes.data, t.size, w, h)
+            r, t, d = addr(ref), addr(test), descs[i]
+            d.reference, d.reference_len, d.test, d.test_len, d.width, d.height = r[1], r[2], t[1], t[2], w, h
         out = (CeScores * n)()
         if test_tables is not None:
             luts = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in test_tables])

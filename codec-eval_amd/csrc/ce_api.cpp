@@ -140,8 +140,7 @@ int ce_build_xcd_list(ce_batch *b, uint32_t n_pairs, uint32_t n_tiles, ce_xcd_li
         CE_HIP(ctx, hipMalloc(&L->d, flat.size() * sizeof(uint2)));
         L->cap = (uint32_t)flat.size();
     }
-    CE_HIP(ctx, hipMemcpyAsync(L->d, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is pageable and goes out of scope
+    if (int rc = ce_upload_table(b, L->d, flat.data(), flat.size() * sizeof(uint2))) return rc;  // `flat` is pageable and goes out of scope
     L->len = (uint32_t)flat.size();
     L->version = b->pair_ref_version;
     L->pairs = n_pairs;
@@ -156,6 +155,22 @@ void ce_free_xcd_list(ce_xcd_list *L)
 }
 
 thread_local hipStream_t ce_tls_stream = nullptr;  // ce_internal.h: CE_STREAM
+
+// Host table -> device memory of batch `b`, complete when this returns.  Work lists and the pair -> reference table are
+// built in pageable vectors, so the host has to wait for the copy - but NOT for the context's stream: round 2 copied on
+// that stream and drained it, which made every ce_eval_batch chunk whose pair count differs from the slot's previous one
+// wait for the kernels of the chunk before it, and its uploads no longer overlapped them (profiles/r03_experiments.md
+// section 17: 141 -> see there).  The copy runs on the batch's upload stream, behind the previous launch of THIS batch
+// (which may still read the old table) and behind the image uploads already queued there.
+int ce_upload_table(ce_batch *b, void *dst, const void *src, size_t bytes)
+{
+    ce_ctx *ctx = b->ctx;
+    if (bytes == 0) return CE_OK;
+    CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));  // never recorded = no wait
+    CE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->up_stream));
+    CE_HIP(ctx, hipStreamSynchronize(b->up_stream));
+    return CE_OK;
+}
 
 hipStream_t ce_ctx_aux_stream(ce_ctx *ctx, int which)
 {
@@ -299,6 +314,7 @@ void ce_ctx_destroy(ce_ctx *ctx)
     prof_drain(ctx);
     for (auto &kv : ctx->shape_pool) ce_batch_destroy(kv.second);
     ctx->shape_pool.clear();
+    if (ctx->up2_stream) hipStreamSynchronize(ctx->up2_stream), hipStreamDestroy(ctx->up2_stream), hipEventDestroy(ctx->ev_up2);
     for (auto &st : ctx->aux_stream)  // after the last batch that may still drain them
         if (st) hipStreamSynchronize(st), hipStreamDestroy(st), st = nullptr;
     for (hipEvent_t ev : ctx->event_pool) hipEventDestroy(ev);
@@ -513,8 +529,25 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
             CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
             b->run_pending = false;
         }
-        for (const auto &j : jobs)
-            CE_HIP(ctx, hipMemcpyAsync(j.dst, j.src, b->img_bytes, hipMemcpyHostToDevice, b->up_stream));
+        static const int n_up = [] {
+            const char *e = std::getenv("CE_UPLOAD_STREAMS");
+            return e ? std::max(1, std::min(2, std::atoi(e))) : 2;  // measured with the ramp below: 99.9 -> 95.4 ms per 2000 pairs
+        }();
+        if (n_up == 2 && jobs.size() >= 16) {
+            if (!ctx->up2_stream) {
+                CE_HIP(ctx, hipStreamCreateWithFlags(&ctx->up2_stream, hipStreamNonBlocking));
+                CE_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up2, hipEventDisableTiming));
+            }
+            CE_HIP(ctx, hipEventRecord(ctx->ev_up2, b->up_stream));  // behind whatever up_stream already waits for
+            CE_HIP(ctx, hipStreamWaitEvent(ctx->up2_stream, ctx->ev_up2, 0));
+            for (size_t i = 0; i < jobs.size(); i++)
+                CE_HIP(ctx, hipMemcpyAsync(jobs[i].dst, jobs[i].src, b->img_bytes, hipMemcpyHostToDevice, (i & 1) ? ctx->up2_stream : b->up_stream));
+            CE_HIP(ctx, hipEventRecord(ctx->ev_up2, ctx->up2_stream));
+            CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, ctx->ev_up2, 0));
+        } else {
+            for (const auto &j : jobs)
+                CE_HIP(ctx, hipMemcpyAsync(j.dst, j.src, b->img_bytes, hipMemcpyHostToDevice, b->up_stream));
+        }
         b->uploads_pending = true;
         return CE_OK;
     }
@@ -763,8 +796,7 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         for (size_t r = 0; r <= R; r++) table[2 * P + r] = count[r];
         std::vector<uint32_t> fill(count.begin(), count.end() - 1);
         for (uint32_t i = 0; i < P; i++) table[2 * P + R + 1 + fill[b->h_pair_ref[i]]++] = i;
-        CE_HIP(ctx, hipMemcpyAsync(b->d_pair_ref, table.data(), sizeof(uint32_t) * table.size(), hipMemcpyHostToDevice, ctx->stream));
-        CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `table` is pageable
+        if (int rc = ce_upload_table(b, b->d_pair_ref, table.data(), sizeof(uint32_t) * table.size())) return rc;  // `table` is pageable
         b->pair_ref_dirty = false;
     }
     uint32_t n_refs_used = 0;
@@ -925,6 +957,10 @@ int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_
         if (joined & (1u << k)) CE_HIP(ctx, hipStreamWaitEvent(base, b->ev_join[k], 0));
     b->last_n_pairs = n_pairs;
     b->last_mask = metric_mask;
+    // the scores come back behind the last kernel of THIS launch and ev_run marks them: ce_batch_collect waits for the event,
+    // not for the stream (round 2 copied at collect time and drained the context's stream, so collecting one batch waited
+    // for every batch launched after it - in ce_eval_batch the next chunk's upload then started only when the device was idle)
+    CE_HIP(ctx, hipMemcpyAsync(b->h_scores, b->d_scores, sizeof(ce_dev_scores) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     CE_HIP(ctx, hipEventRecord(b->ev_run, ctx->stream));
     b->run_pending = true;
     if (!b->counted_in_flight) {
@@ -940,9 +976,8 @@ int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out)
     ce_ctx *ctx = b->ctx;
     if (n_pairs == 0 || n_pairs > b->max_pairs) return fail(ctx, CE_ERR_INVALID_ARG, "n_pairs out of range");
     CE_HIP(ctx, hipSetDevice(ctx->device));
-    CE_HIP(ctx, hipMemcpyAsync(b->h_scores, b->d_scores, sizeof(ce_dev_scores) * n_pairs, hipMemcpyDeviceToHost,
-                               ctx->stream));
-    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_pairs > b->last_n_pairs) return fail(ctx, CE_ERR_INVALID_ARG, "collect asks for more pairs than the last launch ran");
+    CE_HIP(ctx, hipEventSynchronize(b->ev_run));  // the launch's kernels and the copy of its scores into h_scores (ce_batch_launch)
     b->run_pending = false;
     leave_flight(b);
     const uint32_t mask = b->last_mask;
@@ -1047,7 +1082,11 @@ static size_t chunk_budget(ce_ctx *ctx)
                               (pb->ba_ready ? CE_METRIC_BUTTERAUGLI : 0u);
         pooled += ce_estimate_batch_bytes(pb->w, pb->h, pb->max_refs, pb->max_pairs, held);
     }
-    return (size_t)((double)(free_b + pooled) * 0.8 / ce_ctx::kPoolRing);
+    // ... and no chunk asks for more than kChunkBytesMax: on a 288 GB device a third of the free memory is a 70+ GB batch whose
+    // hipMalloc calls alone take seconds (measured: 2000 pairs of 512x512, three metrics - first call 3.7 s + 6.5 s for the
+    // second with 73 GB chunks, 0.19 s with 48 GiB ones; steady state 128 ms vs 139 ms; profiles/r03_experiments.md §17)
+    const size_t share = (size_t)((double)(free_b + pooled) * 0.8 / ce_ctx::kPoolRing);
+    return std::min(share, ce_ctx::kChunkBytesMax);
 }
 
 // free every pooled batch that has nothing in flight (called when a new one does not fit)
@@ -1159,16 +1198,34 @@ int ce_eval_batch_lut(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, const ce
                                     ce_estimate_batch_bytes(kv.first.first, kv.first.second, 1, 1, metric_mask);  // a pair with a reference of its own
             const size_t cap = std::max<size_t>(1, chunk_budget(ctx) / std::max<size_t>(per_pair, 1));
             target = std::min(target, cap);
+            // a pooled batch of this shape that is a little smaller than today's target (the estimate above and what
+            // hipMemGetInfo reports move by a few per cent between calls) is used as it is rather than reallocated
+            {
+                auto it0 = ctx->shape_pool.find(std::make_tuple(kv.first.first, kv.first.second, 0u));
+                if (it0 != ctx->shape_pool.end() && it0->second->max_pairs < target && (size_t)it0->second->max_pairs * 4 >= target * 3)
+                    target = it0->second->max_pairs;
+            }
             std::vector<std::vector<size_t>> split;
             for (auto &g : groups)
                 for (size_t o = 0; o < g.size(); o += target)
                     split.emplace_back(g.begin() + o, g.begin() + std::min(g.size(), o + target));
             groups.swap(split);
         }
+        // The upload of the FIRST chunk of a call overlaps nothing, so a bucket that needs several chunks starts with a
+        // small one and grows geometrically up to the target (an upload costs about half of what the kernels of the same
+        // pairs do, so each chunk's kernels still cover the upload of the next, twice as large).  CE_EVAL_BATCH_RAMP = pairs
+        // of the first chunk (0 = every chunk at the target).
+        static const size_t ramp0 = [] {
+            const char *e = std::getenv("CE_EVAL_BATCH_RAMP");
+            return (size_t)(e ? std::max(0, std::atoi(e)) : 64);  // 2000 pairs of 512x512: off 106.5 ms, 32 -> 102.1, 64 -> 100.0, 128 -> 101.1
+        }();
+        const bool several = idx.size() > target;
+        size_t limit = (several && ramp0 && ring == 0) ? std::min(ramp0, target) : target;
         size_t g0 = 0;
         while (g0 < groups.size()) {
             size_t g1 = g0, count = 0;
-            while (g1 < groups.size() && (count == 0 || count + groups[g1].size() <= target)) count += groups[g1++].size();
+            while (g1 < groups.size() && (count == 0 || count + groups[g1].size() <= limit)) count += groups[g1++].size();
+            limit = std::min(target, limit * 2);
             // a ring slot may still be in flight from an earlier chunk of this call: collect it first
             const uint32_t slot = ring++ % ce_ctx::kPoolRing;
             for (auto &c : chunks)
@@ -1181,7 +1238,9 @@ int ce_eval_batch_lut(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, const ce
                     c.b = nullptr;  // collected
                 }
             ce_batch *b = nullptr;
-            int rc = shape_batch(ctx, kv.first.first, kv.first.second, (uint32_t)count, slot, &b);
+            // (a bucket cut into several chunks sizes every ring slot for the target: the small first chunks do not make a
+            // slot that a later, larger chunk of the same call would have to reallocate)
+            int rc = shape_batch(ctx, kv.first.first, kv.first.second, (uint32_t)(several ? std::max(count, target) : count), slot, &b);
             if (rc != CE_OK) return rc;
             b->pool_key = std::make_tuple(kv.first.first, kv.first.second, slot);
             chunk ch{b, {}};

@@ -75,6 +75,8 @@ struct ce_ctx {
     // scratch pool for the host-buffer entry points: up to kPoolRing batches per shape (ce_eval_batch streams a large
     // bucket through them in chunks so that the upload of one chunk overlaps the kernels of the previous one)
     static constexpr uint32_t kPoolRing = 3;
+    // largest device footprint one ce_eval_batch chunk is sized for (ce_api.cpp: chunk_budget)
+    static constexpr size_t kChunkBytesMax = (size_t)48 << 30;
     std::map<std::tuple<uint32_t, uint32_t, uint32_t>, ce_batch *> shape_pool;
 
     // grow-only scratch of the leaf entry points that take one host image and return one (ce_xyb_roundtrip,
@@ -90,6 +92,8 @@ struct ce_ctx {
     // before it (profiles/r03_experiments.md section 15).
     enum { AUX_METRIC0 = 0, AUX_SSIM2_L0 = 3, AUX_SSIM2_L0B = 4, AUX_BA_HALF = 5, AUX_COUNT = 6 };
     hipStream_t aux_stream[AUX_COUNT] = {};
+    hipStream_t up2_stream = nullptr;  // second DMA stream of ce_eval_batch's page-locked uploads (CE_UPLOAD_STREAMS=2)
+    hipEvent_t ev_up2 = nullptr;
 
     // two parked host threads that enqueue the other metric chains of a forked batch (ce_api.cpp: ce_fork_helpers); made on
     // the first forked launch, joined by ce_ctx_destroy
@@ -232,6 +236,9 @@ struct ce_batch {
             return CE_ERR_BACKEND;                                                                 \
         }                                                                                          \
     } while (0)
+
+// host table -> device memory of `b`, complete on return, without draining the context's stream (ce_api.cpp)
+int ce_upload_table(ce_batch *b, void *dst, const void *src, size_t bytes);
 
 // the context's auxiliary stream `which` (ce_ctx::AUX_*), made on first use; nullptr + ctx->err on failure (ce_api.cpp)
 hipStream_t ce_ctx_aux_stream(ce_ctx *ctx, int which);

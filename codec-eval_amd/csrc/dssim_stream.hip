@@ -435,8 +435,7 @@ int build_stream_list(ce_batch *b, uint32_t n_pairs, uint32_t strips, uint32_t r
         CE_HIP(ctx, hipMalloc(&L->d, flat.size() * sizeof(uint2)));
         L->cap = (uint32_t)flat.size();
     }
-    CE_HIP(ctx, hipMemcpyAsync(L->d, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is pageable and goes out of scope
+    if (int rc = ce_upload_table(b, L->d, flat.data(), flat.size() * sizeof(uint2))) return rc;  // `flat` is pageable and goes out of scope
     L->len = (uint32_t)flat.size();
     L->version = b->pair_ref_version;
     L->pairs = n_pairs;

@@ -835,8 +835,7 @@ static int build_one_list(ce_batch *b, uint32_t n_pairs, uint32_t n_blocks, uint
         CE_HIP(ctx, hipMalloc(d_list, flat.size() * sizeof(uint2)));
         *cap = (uint32_t)flat.size();
     }
-    CE_HIP(ctx, hipMemcpyAsync(*d_list, flat.data(), flat.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
-    CE_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `flat` is pageable and goes out of scope
+    if (int rc = ce_upload_table(b, *d_list, flat.data(), flat.size() * sizeof(uint2))) return rc;  // `flat` is pageable and goes out of scope
     *len = (uint32_t)flat.size();
     return CE_OK;
 }

@@ -192,8 +192,10 @@ int ce_batch_bind_pair(ce_batch *b, uint32_t pair_index, uint32_t ref_index);
 /* run the hot path over pairs [0, n_pairs); blocks until scores are on the host */
 int ce_batch_run(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags, float intensity_target,
                  ce_scores *out);
-/* same, without the final synchronise + D2H (for back-to-back timed steps); scores are
- * fetched by ce_batch_collect */
+/* same, without the final wait (for back-to-back timed steps and pipelines of several batches): the launch queues the
+ * kernels and, behind them, the copy of the scores into the batch's page-locked buffer; ce_batch_collect waits for THAT
+ * launch only (not for batches launched after it on the same context) and converts the first n_pairs scores
+ * (n_pairs <= the launched count, CE_ERR_INVALID_ARG otherwise) */
 int ce_batch_launch(ce_batch *b, uint32_t n_pairs, uint32_t metric_mask, uint32_t flags,
                     float intensity_target);
 int ce_batch_collect(ce_batch *b, uint32_t n_pairs, ce_scores *out);

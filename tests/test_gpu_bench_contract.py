@@ -61,7 +61,9 @@ def test_single_gpu_line():
     assert 0.0 < c["per_thread_efficiency"] <= 1.3
     assert d["value"] > c["value"] and all(v < 1e-4 for v in d["max_rel_dev_vs_oracle"].values())
     e = d["end_to_end"]
-    assert e["unit"] == "MP/s" and 0 < e["value"] <= d["kodak_only"]["value"] * 1.05
+    # the host-buffer route runs the same workload with its uploads inside the timing: slower than the resident headline, but
+    # the uploads overlap the kernels, so not by the 2x a serial upload + kernels would cost
+    assert e["unit"] == "MP/s" and e["grid"].startswith("the whole workload") and 0.5 * d["value"] < e["value"] <= d["value"] * 1.02
 
 
 def _check_two_rank_line(out):
