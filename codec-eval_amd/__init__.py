@@ -122,6 +122,8 @@ _PROTOTYPES = [
     ("ce_eval_batch", _i, [_vp, _sz, C.POINTER(CePairDesc), _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_estimate_batch_bytes", _sz, [_u32, _u32, _u32, _u32, _u32]),
     ("ce_ctx_memory_info", _i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("ce_host_alloc", _i, [_vp, _sz, C.POINTER(_vp)]),
+    ("ce_host_free", _i, [_vp, _vp]),
     ("ce_eval_batch_lut", _i, [_vp, _sz, C.POINTER(CePairDesc), C.POINTER(_vp), _u32, _u32, _f32, C.POINTER(CeScores)]),
     ("ce_batch_create", _i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("ce_batch_destroy", None, [_vp]),
@@ -199,6 +201,44 @@ def _buf(a) -> np.ndarray:
     if arr.dtype != np.uint8:
         raise TypeError("pixel buffers must be uint8")
     return np.ascontiguousarray(arr).reshape(-1)
+
+
+def _pinned_block(address: int, nbytes: int):
+    """One ce_host_alloc block as a ctypes array (buffer protocol: numpy keeps it alive through `.base`) that frees the block
+    when the last array on it is gone."""
+    def _free(self):
+        a, self._ce_address = getattr(self, "_ce_address", 0), 0
+        if a:
+            lib().ce_host_free(None, a)
+    cls = type("CePinnedBlock", (C.c_ubyte * nbytes,), {"__del__": _free})
+    blk = cls.from_address(address)
+    blk._ce_address = address
+    return blk
+
+
+class PairList:
+    """The ce_pair_desc array of a grid, built once: (reference, test, width, height) tuples -> descriptors that borrow the
+    callers' buffers (kept alive here).  Identical reference objects share one descriptor address, which is what makes
+    ce_eval_batch upload a reference once for all its distorted images."""
+
+    def __init__(self, pairs: Sequence[tuple]):
+        self.n = len(pairs)
+        self.descs = (CePairDesc * self.n)()
+        keep = {}  # id(buffer) -> (flat view, address, length, the object): a reference shared by many pairs is looked at once
+
+        def addr(a):
+            e = keep.get(id(a))
+            if e is None:
+                v = _buf(a)
+                e = keep[id(a)] = (v, v.__array_interface__["data"][0], v.size, a)
+            return e
+        for i, (ref, test, w, h) in enumerate(pairs):
+            r, t, d = addr(ref), addr(test), self.descs[i]
+            d.reference, d.reference_len, d.test, d.test_len, d.width, d.height = r[1], r[2], t[1], t[2], w, h
+        self._keep = keep
+
+    def __len__(self):
+        return self.n
 
 
 # ---- MetricConfig / MetricResult mirrors (src/metrics/mod.rs:46-149) -----------------------
@@ -409,29 +449,27 @@ class Context:
                                        config.mask, config.flags, intensity_target, C.byref(s)))
         return MetricResult.from_c(s)
 
-    def eval_batch(self, pairs: Sequence[tuple], config: MetricConfig,
-                   intensity_target: float = DEFAULT_INTENSITY_TARGET, test_tables: Optional[Sequence] = None) -> List[CeScores]:
-        """pairs: (reference, test, width, height).  The (codec x quality) grid of session.rs:375-376.
-        test_tables: optional per-pair ColorTable (or None) applied to the distorted image on the device."""
-        n = len(pairs)
-        descs = (CePairDesc * n)()
-        keep = {}  # id(buffer) -> (flat view, address, length): a reference shared by many pairs is looked at once
+    def host_buffer(self, nbytes: int) -> np.ndarray:
+        """`nbytes` of page-locked host memory as a flat uint8 array (ce_host_alloc; freed when the array and every view of
+        it are gone): images placed here are uploaded by DMA straight from the buffer, overlapped with the kernels."""
+        p = C.c_void_p()
+        self._check(lib().ce_host_alloc(self._h, nbytes, C.byref(p)))
+        return np.frombuffer(_pinned_block(p.value, nbytes), dtype=np.uint8)
 
-        def addr(a):
-            e = keep.get(id(a))
-            if e is None:
-                v = _buf(a)
-                e = keep[id(a)] = (v, v.__array_interface__["data"][0], v.size, a)
-            return e
-        for i, (ref, test, w, h) in enumerate(pairs):
-            r, t, d = addr(ref), addr(test), descs[i]
-            d.reference, d.reference_len, d.test, d.test_len, d.width, d.height = r[1], r[2], t[1], t[2], w, h
+    def eval_batch(self, pairs, config: MetricConfig,
+                   intensity_target: float = DEFAULT_INTENSITY_TARGET, test_tables: Optional[Sequence] = None) -> List[CeScores]:
+        """pairs: (reference, test, width, height) tuples, or a PairList built from them once (a caller that scores the same
+        buffers again and again - a decoder writing into fixed page-locked images - then pays the descriptor marshalling
+        once, as a compiled caller of ce_eval_batch does).  The (codec x quality) grid of session.rs:375-376.
+        test_tables: optional per-pair ColorTable (or None) applied to the distorted image on the device."""
+        pl = pairs if isinstance(pairs, PairList) else PairList(pairs)
+        n = pl.n
         out = (CeScores * n)()
         if test_tables is not None:
             luts = (C.c_void_p * n)(*[(t._h if t is not None else None) for t in test_tables])
-            self._check(lib().ce_eval_batch_lut(self._h, n, descs, luts, config.mask, config.flags, intensity_target, out))
+            self._check(lib().ce_eval_batch_lut(self._h, n, pl.descs, luts, config.mask, config.flags, intensity_target, out))
         else:
-            self._check(lib().ce_eval_batch(self._h, n, descs, config.mask, config.flags, intensity_target, out))
+            self._check(lib().ce_eval_batch(self._h, n, pl.descs, config.mask, config.flags, intensity_target, out))
         return list(out)
 
     # -- measurement hooks

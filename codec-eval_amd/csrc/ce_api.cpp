@@ -1065,6 +1065,26 @@ int ce_ctx_memory_info(ce_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
     return CE_OK;
 }
 
+int ce_host_alloc(ce_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out || bytes == 0) return CE_ERR_INVALID_ARG;
+    *out = nullptr;
+    CE_HIP(ctx, hipSetDevice(ctx->device));
+    CE_HIP(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return CE_OK;
+}
+
+int ce_host_free(ce_ctx *ctx, void *p)
+{
+    if (!p) return CE_OK;
+    const hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) {
+        if (ctx) ctx->err = std::string("hipHostFree: ") + hipGetErrorString(e);
+        return CE_ERR_BACKEND;
+    }
+    return CE_OK;
+}
+
 // bytes one ce_eval_batch chunk may allocate: CE_EVAL_BATCH_BYTES if set (tests), else a share of what is free now
 static size_t chunk_budget(ce_ctx *ctx)
 {

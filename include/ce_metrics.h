@@ -149,6 +149,14 @@ int ce_eval_batch_lut(ce_ctx *ctx, size_t n, const ce_pair_desc *pairs, const ce
 size_t ce_estimate_batch_bytes(uint32_t width, uint32_t height, uint32_t n_refs, uint32_t n_pairs, uint32_t metric_mask);
 int ce_ctx_memory_info(ce_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 
+/* Page-locked host memory for the images a caller hands to ce_eval_batch / ce_batch_set_*: buffers from here are copied by
+ * the DMA engines straight from the caller's memory (one asynchronous copy per image, overlapped with the kernels of the
+ * previous chunk); any other host pointer is first copied through the library's own page-locked staging ring by host
+ * threads.  A decoder writes its output into such a buffer and scores it in place - the role of the cudarse pinned buffers
+ * behind GpuSsim2 (crates/codec-iter/src/gpu.rs:96-108).  Freed with ce_host_free (before or after the context is gone). */
+int ce_host_alloc(ce_ctx *ctx, size_t bytes, void **out);
+int ce_host_free(ce_ctx *ctx, void *p);
+
 /* ---- HBM-resident grid (what bench.py times; inputs already on device) ---------- */
 /* One shape, up to max_refs reference images and max_pairs (reference, test) items. */
 int ce_batch_create(ce_ctx *ctx, uint32_t width, uint32_t height, uint32_t max_refs, uint32_t max_pairs,

@@ -18,9 +18,11 @@ def test_estimate_is_monotone_and_covers_a_real_batch(gpu_ctx, ce, workloads):
     cfg = ce.MetricConfig.all()
     e = lambda r, p, c=cfg: ce.estimate_batch_bytes(256, 192, r, p, c)
     assert e(1, 1) < e(1, 2) < e(2, 2) and e(1, 4, ce.MetricConfig.fast()) < e(1, 4, ce.MetricConfig(ssimulacra2=True)) < e(1, 4)
+    g = workloads._grid("t", 256, 192, 2, 50, (40, 80))
+    # what the first launches of a process load once (code objects, the context's tables and streams) is not the batch's
+    gpu_ctx.calculate_metrics(g.references[0], g.pairs[0][1], 256, 192, cfg)
     free0, total = gpu_ctx.memory_info()
     assert 0 < free0 <= total
-    g = workloads._grid("t", 256, 192, 2, 50, (40, 80))
     b = ce.Batch(gpu_ctx, 256, 192, 2, 4)
     for i, r in enumerate(g.references):
         b.set_reference(i, r)
@@ -88,3 +90,66 @@ def test_session_splits_a_shape_into_batches_that_fit(gpu_ctx, ce, workloads, tm
         else:
             os.environ["CE_SESSION_BATCH_BYTES"] = old
     assert len(want) == 12 and all(v is not None for row in want for v in row)
+
+
+def test_collect_waits_for_its_own_launch_only(gpu_ctx, ce, workloads):
+    """Two batches launched back to back on ONE context, collected in the reverse order: ce_batch_collect waits for the
+    event of its batch's launch (the scores are copied behind that launch's kernels), so either order returns each batch's
+    own scores; asking for more pairs than were launched, or collecting a batch that never ran, is an error."""
+    cfg = ce.MetricConfig.all()
+    grids = [workloads._grid("a", 160, 96, 2, 70, (40, 85)), workloads._grid("b", 96, 160, 1, 90, (30, 60, 95))]
+    batches, want = [], []
+    for g in grids:
+        b = ce.Batch(gpu_ctx, g.width, g.height, len(g.references), len(g.pairs))
+        for i, r in enumerate(g.references):
+            b.set_reference(i, r)
+        for k, (ri, t) in enumerate(g.pairs):
+            b.set_test(k, ri, t)
+        with pytest.raises(ce.CodecEvalError):
+            b.collect(1)  # nothing launched yet
+        want.append([(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli) for s in b.run(len(g.pairs), cfg)])
+        batches.append(b)
+    for order in ((0, 1), (1, 0)):
+        for b, g in zip(batches, grids):
+            b.launch(len(g.pairs), cfg)
+        got = {}
+        for j in order[::-1]:
+            got[j] = [(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli) for s in batches[j].collect(len(grids[j].pairs))]
+        assert [got[0], got[1]] == want
+    # a prefix of the launched pairs is fine, more than were launched is not
+    batches[0].launch(2, cfg)
+    assert [(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli) for s in batches[0].collect(1)] == want[0][:1]
+    with pytest.raises(ce.CodecEvalError):
+        batches[0].collect(3)
+    for b in batches:
+        b.close()
+
+
+def test_eval_batch_ramp_and_ring_reuse_keep_every_score(gpu_ctx, ce, workloads):
+    """A bucket cut into many chunks (first chunk small, doubling; ring slots reused while later chunks are in flight; the
+    page-locked uploads split over two streams) returns exactly the scores of the one-chunk call, in the caller's order."""
+    w, h = 96, 64
+    refs = [workloads.make_reference(w, h, 500 + i) for i in range(12)]
+    pinned = gpu_ctx.host_buffer(12 * 5 * h * w * 3).reshape(12 * 5, h * w * 3)  # ce_host_alloc: the DMA route
+    items = []
+    for i, r in enumerate(refs):
+        pinned[5 * i][:] = r.reshape(-1)
+        for k, q in enumerate((35, 60, 80, 95)):
+            pinned[5 * i + 1 + k][:] = workloads.distort(r, q).reshape(-1)
+            items.append((pinned[5 * i], pinned[5 * i + 1 + k], w, h))
+    cfg = ce.MetricConfig.all()
+    want = [(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli, s.status) for s in gpu_ctx.eval_batch(items, cfg)]
+    per_pair = ce.estimate_batch_bytes(w, h, 2, 2, cfg) - ce.estimate_batch_bytes(w, h, 1, 1, cfg)
+    saved = {k: os.environ.get(k) for k in ("CE_EVAL_BATCH_BYTES", "CE_EVAL_BATCH_RAMP")}
+    try:
+        os.environ["CE_EVAL_BATCH_BYTES"] = str(per_pair * 8)  # 48 pairs in chunks of <= 8: the three ring slots are reused twice
+        got = [(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli, s.status) for s in gpu_ctx.eval_batch(items, cfg)]
+        assert got == want
+        assert [(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli, s.status) for s in gpu_ctx.eval_batch(items[::-1], cfg)] == want[::-1]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert all(s[4] == 0 for s in want)
