@@ -524,26 +524,40 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
             all_pinned = false;
             break;
         }
+    // One stream moves a 786 KB image in 38 us (20.6 GB/s): the 1.88 GB of the Kodak + CID22 sweep would take as long as its
+    // kernels.  The copies of a chunk therefore alternate between the batch's upload stream and a second one of the context,
+    // which is fenced on both sides so that everything else keeps seeing "the uploads are on up_stream".
+    static const int n_up = [] {
+        const char *e = std::getenv("CE_UPLOAD_STREAMS");
+        return e ? std::max(1, std::min(2, std::atoi(e))) : 2;  // 2000 pairs of 512x512, page-locked: 99.9 -> 95.4 ms; pageable: see r03_experiments 17
+    }();
+    const bool two_up = n_up == 2 && jobs.size() >= 16;
+    auto up2_begin = [&]() -> int {
+        if (!ctx->up2_stream) {
+            CE_HIP(ctx, hipStreamCreateWithFlags(&ctx->up2_stream, hipStreamNonBlocking));
+            CE_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up2, hipEventDisableTiming));
+        }
+        CE_HIP(ctx, hipEventRecord(ctx->ev_up2, b->up_stream));  // behind whatever up_stream already waits for
+        CE_HIP(ctx, hipStreamWaitEvent(ctx->up2_stream, ctx->ev_up2, 0));
+        return CE_OK;
+    };
+    auto up2_end = [&]() -> int {
+        CE_HIP(ctx, hipEventRecord(ctx->ev_up2, ctx->up2_stream));
+        CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, ctx->ev_up2, 0));
+        return CE_OK;
+    };
     if (all_pinned) {
         if (b->run_pending) {
             CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
             b->run_pending = false;
         }
-        static const int n_up = [] {
-            const char *e = std::getenv("CE_UPLOAD_STREAMS");
-            return e ? std::max(1, std::min(2, std::atoi(e))) : 2;  // measured with the ramp below: 99.9 -> 95.4 ms per 2000 pairs
-        }();
-        if (n_up == 2 && jobs.size() >= 16) {
-            if (!ctx->up2_stream) {
-                CE_HIP(ctx, hipStreamCreateWithFlags(&ctx->up2_stream, hipStreamNonBlocking));
-                CE_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_up2, hipEventDisableTiming));
-            }
-            CE_HIP(ctx, hipEventRecord(ctx->ev_up2, b->up_stream));  // behind whatever up_stream already waits for
-            CE_HIP(ctx, hipStreamWaitEvent(ctx->up2_stream, ctx->ev_up2, 0));
+        if (two_up) {
+            int rc = up2_begin();
+            if (rc != CE_OK) return rc;
             for (size_t i = 0; i < jobs.size(); i++)
                 CE_HIP(ctx, hipMemcpyAsync(jobs[i].dst, jobs[i].src, b->img_bytes, hipMemcpyHostToDevice, (i & 1) ? ctx->up2_stream : b->up_stream));
-            CE_HIP(ctx, hipEventRecord(ctx->ev_up2, ctx->up2_stream));
-            CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, ctx->ev_up2, 0));
+            rc = up2_end();
+            if (rc != CE_OK) return rc;
         } else {
             for (const auto &j : jobs)
                 CE_HIP(ctx, hipMemcpyAsync(j.dst, j.src, b->img_bytes, hipMemcpyHostToDevice, b->up_stream));
@@ -564,11 +578,16 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
         CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
         b->run_pending = false;
     }
+    if (two_up) {
+        int rc = up2_begin();
+        if (rc != CE_OK) return rc;
+    }
     std::atomic<size_t> next{0};
     std::atomic<int> err{(int)hipSuccess};
     const int device = ctx->device;
     auto worker = [&](int t) {
         if (hipSetDevice(device) != hipSuccess) return;
+        const hipStream_t us = (two_up && (t & 1)) ? ctx->up2_stream : b->up_stream;  // a worker's two ring slots stay on its stream
         int flip = 0;
         for (;;) {
             const size_t i = next.fetch_add(1);
@@ -579,9 +598,9 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
             if (b->stage_busy[k]) e = hipEventSynchronize(b->ev_stage[k]);
             if (e == hipSuccess) {
                 std::memcpy(b->h_stage[k], jobs[i].src, b->img_bytes);
-                e = hipMemcpyAsync(jobs[i].dst, b->h_stage[k], b->img_bytes, hipMemcpyHostToDevice, b->up_stream);
+                e = hipMemcpyAsync(jobs[i].dst, b->h_stage[k], b->img_bytes, hipMemcpyHostToDevice, us);
             }
-            if (e == hipSuccess) e = hipEventRecord(b->ev_stage[k], b->up_stream);
+            if (e == hipSuccess) e = hipEventRecord(b->ev_stage[k], us);
             b->stage_busy[k] = true;
             if (e != hipSuccess) {
                 err.store((int)e);
@@ -600,6 +619,10 @@ static int upload_many(ce_batch *b, const std::vector<upload_job> &jobs)
     worker(0);
     for (auto &th : pool) th.join();
     b->uploads_pending = true;
+    if (two_up) {
+        int rc = up2_end();
+        if (rc != CE_OK) return rc;
+    }
     if (err.load() != (int)hipSuccess) {
         ctx->err = std::string("upload: ") + hipGetErrorString((hipError_t)err.load());
         return CE_ERR_BACKEND;
