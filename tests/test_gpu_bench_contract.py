@@ -64,6 +64,8 @@ def test_single_gpu_line():
     # the host-buffer route runs the same workload with its uploads inside the timing: slower than the resident headline, but
     # the uploads overlap the kernels, so not by the 2x a serial upload + kernels would cost
     assert e["unit"] == "MP/s" and e["grid"].startswith("the whole workload") and 0.5 * d["value"] < e["value"] <= d["value"] * 1.02
+    # ... and from ordinary host memory (host threads stage every image) the route still keeps the device mostly busy
+    assert 0.4 * d["value"] < e["pageable"]["value"] <= e["value"] * 1.05
 
 
 def _check_two_rank_line(out):
