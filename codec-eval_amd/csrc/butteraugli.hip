@@ -22,15 +22,28 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
-#include <utility>
 
 #include "ce_internal.h"
-#include "ba_common.h"
 
 namespace {
 
 constexpr int TPB = 256;
-using namespace ce_ba;  // PSY, the plane names, geom, blur_kernel, slot_of (ba_common.h: shared with ba_stream.hip)
+constexpr int PSY = 10;  // uhf0 uhf1 hf0 hf1 mf0 mf1 mf2 lf0 lf1 lf2
+enum { UHF0 = 0, UHF1, HF0, HF1, MF0, MF1, MF2, LF0, LF1, LF2 };
+
+struct geom {
+    uint32_t w, h, pitch;
+    size_t plane;
+};
+
+struct blur_kernel {
+    int len;
+    float k[40];
+    // 1 / (sum of the valid weights) for an output d pixels from the low / high border of a line that is at least
+    // `len` long, summed on the host in the order the pixel loop would sum them (low border: taps off-d .. len-1,
+    // high border: taps 0 .. off+d)
+    float lo[16], hi[16];
+};
 
 #define BA_XY                                                           \
     const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);            \
@@ -38,6 +51,10 @@ using namespace ce_ba;  // PSY, the plane names, geom, blur_kernel, slot_of (ba_
     if (x >= g.w || y >= g.h) return;                                   \
     const size_t o = (size_t)y * g.pitch + x
 
+__device__ __forceinline__ uint32_t slot_of(uint32_t z, uint32_t n_refs_used, uint32_t max_refs)
+{
+    return z < n_refs_used ? z : max_refs + (z - n_refs_used);
+}
 
 // ---- separable blurs ------------------------------------------------------------------------------------
 // unit stride `us` planes per unit; planes [first, first+n) of each unit are processed; z = unit * n + k
@@ -1173,8 +1190,6 @@ void ce_butteraugli_free(ce_batch *b)
         hipFree(b->ba_mask[l]);
         hipFree(b->ba_mask_vals[l]);
         b->ba_mask_vals[l] = nullptr;
-        hipFree(b->ba_lf_scale[l]);
-        b->ba_lf_scale[l] = nullptr;
         ce_free_xcd_list(&b->ba_work[l]);
         b->ba_psy[l] = b->ba_diff[l] = b->ba_mask[l] = nullptr;
     }
@@ -1218,24 +1233,6 @@ static int ba_allocate(ce_batch *b)
     for (int l = 0; l < b->ba_levels; l++) {
         CE_HIP(ctx, hipMalloc(&b->ba_mask[l], slots * b->ba[l].plane * sizeof(float)));
         CE_HIP(ctx, hipMalloc(&b->ba_mask_vals[l], (size_t)b->max_refs * 2 * b->ba[l].plane * sizeof(float)));
-    }
-    // the LF column pass's per-row border scale: 1 / (sum of the 33-tap kernel's weights that fall inside the image for output
-    // row y), the weights summed in ascending tap order as conv_line_renorm does (all 33 of them for an interior row)
-    {
-        const blur_kernel kLf = make_kernel(7.15593339443f);
-        const int off = kLf.len / 2;
-        for (int l = 0; l < b->ba_levels; l++) {
-            const int h = (int)b->ba[l].h;
-            std::vector<float> scale(h);
-            for (int y = 0; y < h; y++) {
-                float weight = 0.0f;
-                for (int j = std::max(y - off, 0); j <= std::min(y + off, h - 1); j++) weight += kLf.k[j - y + off];
-                scale[y] = 1.0f / weight;
-            }
-            CE_HIP(ctx, hipMalloc(&b->ba_lf_scale[l], sizeof(float) * h));
-            int rc = ce_upload_table(b, b->ba_lf_scale[l], scale.data(), sizeof(float) * h);
-            if (rc != CE_OK) return rc;
-        }
     }
     b->ba_blocks = ((b->ba[0].w + 63) / 64) * ((b->ba[0].h + 3) / 4);
     CE_HIP(ctx, hipMalloc(&b->ba_blk_max, P * b->ba_blocks * sizeof(float)));
@@ -1354,17 +1351,7 @@ int ce_launch_butteraugli(ce_batch *b, const uint8_t *d_refs, uint32_t n_refs_us
                 return e && std::atoi(e) == 64 ? 64 : 32;
             }();
             const dim3 gvs32((g.w + 63) / 64, (g.h + 31) / 32, nz);
-            // LF column pass: the streaming kernel (17 multiplies + 33 adds per output) unless CE_BA_LF_STREAM=0.  A wave walks a
-            // whole column of its strip when that still gives the chip ~6 waves per SIMD; otherwise the column is cut into
-            // segments (each re-reads 32 rows of halo and re-forms their products)
-            static const bool lf_stream = [] {
-                const char *e = std::getenv("CE_BA_LF_STREAM");
-                return !(e && e[0] == '0');
-            }();
-            if (lf_stream) {
-                int rc = ce_ba_launch_v_lf_stream(ctx, st, sA, sC, psy, g, kLf, b->ba_lf_scale[l], n_refs_used, mr, z0, sB, nz);
-                if (rc != CE_OK) return rc;
-            } else if (hv_rows == 32)
+            if (hv_rows == 32)
                 CE_LAUNCH_ON(ctx, st, "ba_blur_v_lf", (k_ba_blur_v_split<33, EPI_LF, false, 32>), gvs32, dim3(TPB), 0, (const float *)sA,
                           (const float *)sC, psy, g, kLf, inv_weight_sum(kLf), n_refs_used, mr, z0, (float *)nullptr, sB);
             else

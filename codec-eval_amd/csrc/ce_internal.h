@@ -213,7 +213,6 @@ struct ce_batch {
     float *ba_s_half[3] = {};
     hipStream_t ba_half_stream = nullptr;
     hipEvent_t ev_ba_fork = nullptr, ev_ba_join = nullptr;
-    float *ba_lf_scale[2] = {};   // [h_l] per-row border scale of the LF column pass (ba_common.h)
     float *ba_mask_vals[2] = {};  // [ref][2][plane_l]    maskval / dc_maskval of the references (FuzzyErosion + mask curves)
     float *ba_blk_max = nullptr;
     double *ba_blk_sums = nullptr;
