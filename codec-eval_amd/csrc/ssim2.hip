@@ -240,8 +240,11 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // ---- row pass, LDS-staged line tiles ------------------------------------------------------
-// One block = 48 rows of one (pair, channel) and 256 threads: thread t < 240 owns one (stream, row) pair -
-// stream t / 48 of {a, b, a*a, b*b, a*b}, row t % 48 - and carries that row's 3-section filter state.
+// One block = HB_ROWS rows of one (pair, channel) and 256 threads: thread t < 5 * HB_ROWS owns one (stream, row) pair -
+// stream t / HB_ROWS of {a, b, a*a, b*b, a*b}, row t % HB_ROWS - and carries that row's 3-section filter state.
+// HB_ROWS = 32 since round 3 (rounds 1-2: 48): 37 KB of LDS instead of 56, four resident blocks per CU instead of two, and the
+// small levels waste fewer rows (a 16-row level 5 filled a third of a 48-row block) - solo, default sweep: level 0 6.43 ->
+// 6.25 ms per step, levels 1-5 2.98 -> 2.39 (24 rows: 6.54 / 2.55, 40 rows: in between); profiles/r03_experiments.md section 20.
 // (Five 64-lane waves, one per stream, look more natural, but a 320-thread block with this much LDS gets ONE
 // resident block per CU on gfx950 - measured with a spin kernel - and then SIMD0 hosts two of its five waves
 // while the other SIMDs idle half the time; 256-thread blocks get two per CU.)
@@ -250,7 +253,7 @@ __device__ __forceinline__ void lds_barrier()
 // access without bank conflicts inside a stream).  The LDS input tile holds two 32-column halves (double buffer);
 // outputs leave through a second LDS tile as coalesced 16-byte row stores of whole 128-byte lines.
 #ifndef CE_HB_ROWS
-#define CE_HB_ROWS 48
+#define CE_HB_ROWS 32
 #endif
 constexpr int HB_ROWS = CE_HB_ROWS, HB_CW = 32, HB_LD = HB_ROWS + 1, HB_THREADS = 256;
 constexpr int HB_LOADS = 2 * HB_ROWS * 8;                    // float4 loads per chunk (two planes)
