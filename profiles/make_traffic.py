@@ -76,9 +76,13 @@ def counters_of(d, cname):
 
 
 def main():
-    tag, fetch_dir, write_dir, sidecar = sys.argv[1:5]
-    stats_dir = sys.argv[5] if len(sys.argv) > 5 else None
-    stats_tag = sys.argv[6] if len(sys.argv) > 6 else tag
+    if sys.argv[1] == "--stats-only":  # python3 profiles/make_traffic.py --stats-only <stats_dir> <stats_tag>: only the kernel_stats condensation
+        tag, fetch_dir, write_dir, sidecar = None, None, None, None
+        stats_dir, stats_tag = sys.argv[2], sys.argv[3]
+    else:
+        tag, fetch_dir, write_dir, sidecar = sys.argv[1:5]
+        stats_dir = sys.argv[5] if len(sys.argv) > 5 else None
+        stats_tag = sys.argv[6] if len(sys.argv) > 6 else tag
     if stats_dir:
         rows = list(csv.DictReader(open(one(stats_dir, "kernel_stats.csv"))))
         with open(os.path.join(HERE, f"{stats_tag}_kernel_stats.csv"), "w", newline="") as fo:
@@ -103,6 +107,8 @@ def main():
                     inst = re.search(r"<([^>]*)>", r["Name"])
                     w.writerow([f"{name} [instance <{inst.group(1) if inst else '?'}>]", r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                                 r["Percentage"], r["MinNs"], r["MaxNs"]])
+    if sidecar is None:
+        return
     side = json.load(open(sidecar))
     rf = importlib.import_module("codec-eval_amd.roofline")
     alg = rf.step_bytes([rf.Bucket(side["width"], side["height"], side["n_refs"], side["n_pairs"])], side["metrics"], side["xyb_roundtrip"])
