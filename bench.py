@@ -698,7 +698,13 @@ def main():
                 hnd = ce.ReferenceHandle(cx, ref, w_, h_)
                 row["ce_ref_compare_all_metrics"] = med(lambda: hnd.compare(test, allm))
                 row["ce_ref_compare_ssimulacra2"] = med(lambda: hnd.compare(test, s2))
+                # the distorted image in page-locked memory (ce_host_alloc: where a decoder would write it): no staging copy
+                tp = cx.host_buffer(test.size)
+                tp[:] = test.reshape(-1)
+                row["ce_ref_compare_all_metrics_page_locked"] = med(lambda: hnd.compare(tp, allm))
+                row["ce_ref_compare_ssimulacra2_page_locked"] = med(lambda: hnd.compare(tp, s2))
                 hnd.close()
+                del tp
                 per_call[f"{w_}x{h_}"] = row
 
     # ---- strong scaling leg (N > 1, default workload): BASELINE configs[3]'s FIXED grid over the same ranks -------------------------------

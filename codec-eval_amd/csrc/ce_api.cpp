@@ -453,6 +453,8 @@ static void invalidate_reference_state(ce_batch *b)
     b->refs_rt_valid = false;
 }
 
+static bool is_pinned_host(const void *p);
+
 static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src, bool allow_inline = true)
 {
     ce_ctx *ctx = b->ctx;
@@ -468,6 +470,13 @@ static int upload(ce_batch *b, uint8_t *dst, const uint8_t *src, bool allow_inli
     if (b->run_pending && !inline_copy) {
         CE_HIP(ctx, hipStreamWaitEvent(b->up_stream, b->ev_run, 0));
         b->run_pending = false;  // ordered from here on
+    }
+    // A BLOCKING entry point (ce_ref_compare*, which collects before it returns) whose caller's image is page-locked
+    // (ce_host_alloc) needs no staging copy: the DMA engine reads the caller's buffer, which outlives the call's kernels.
+    if (b->caller_blocks && is_pinned_host(src)) {
+        CE_HIP(ctx, hipMemcpyAsync(dst, src, b->img_bytes, hipMemcpyHostToDevice, us));
+        if (!inline_copy) b->uploads_pending = true;
+        return CE_OK;
     }
     const int k = b->next_stage;
     b->next_stage = (k + 1) % ce_batch::kStages;
@@ -1500,16 +1509,16 @@ int ce_ref_compare_many(ce_ref *ref, const uint8_t *const *tests, const size_t *
     if (!any_ok) return CE_OK;
     // Rejected items keep their slot (their scores are discarded); every valid test is uploaded to its own slot.
     std::vector<ce_scores> tmp(n_tests);
-    for (uint32_t i = 0; i < n_tests; i++) {
-        if (out[i].status != CE_OK) {
-            int rc = ce_batch_bind_pair(b, i, 0);
-            if (rc != CE_OK) return rc;
-            continue;
-        }
-        int rc = ce_batch_set_test(b, i, 0, tests[i], test_lens[i]);
-        if (rc != CE_OK) return rc;
+    b->caller_blocks = true;  // this call returns after its kernels: page-locked test images are read in place (upload())
+    int rc = CE_OK;
+    for (uint32_t i = 0; i < n_tests && rc == CE_OK; i++)
+        rc = out[i].status != CE_OK ? ce_batch_bind_pair(b, i, 0) : ce_batch_set_test(b, i, 0, tests[i], test_lens[i]);
+    if (rc == CE_OK) rc = ce_batch_run(b, n_tests, metric_mask, ref->flags, intensity_target, tmp.data());
+    if (rc != CE_OK) {  // copies straight from the caller's memory may still be queued: drain them before the buffers go away
+        hipStreamSynchronize(b->up_stream);
+        hipStreamSynchronize(ctx->stream);
     }
-    int rc = ce_batch_run(b, n_tests, metric_mask, ref->flags, intensity_target, tmp.data());
+    b->caller_blocks = false;
     if (rc != CE_OK) return rc;
     for (uint32_t i = 0; i < n_tests; i++)
         if (out[i].status == CE_OK) out[i] = tmp[i];

@@ -225,6 +225,7 @@ struct ce_batch {
     float ba_ref_intensity = 0.0f;
 
     uint32_t last_n_pairs = 0;
+    bool caller_blocks = false;  // set by entry points that collect before returning: page-locked sources need no staging copy
     uint32_t last_mask = 0;
 };
 

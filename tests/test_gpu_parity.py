@@ -269,6 +269,17 @@ def test_reference_handle(gpu_ctx, oracle, ce, workloads):
         assert rel_close(hd.compare(t).ssimulacra2, oracle.ssimulacra2(ref, t, w, h, 1))
     with pytest.raises(ce.DimensionMismatch):
         hd.compare(ref[:10])
+    # a distorted image in page-locked memory (ce_host_alloc) is read in place by the DMA engine - no staging copy - and may be
+    # overwritten by the caller as soon as the (blocking) call returns: same scores as from ordinary memory, call after call
+    pinned = gpu_ctx.host_buffer(w * h * 3)
+    allm = ce.MetricConfig.all()
+    for q in (35, 60, 85, 60):
+        t = workloads.distort(ref, q)
+        pinned[:] = t.reshape(-1)
+        a, b = hd.compare(pinned, allm), hd.compare(t, allm)
+        assert (a.psnr, a.ssimulacra2, a.dssim, a.butteraugli) == (b.psnr, b.ssimulacra2, b.dssim, b.butteraugli)
+        many = hd.compare_many([pinned, t, pinned], allm)
+        assert all((m.ssimulacra2, m.dssim, m.butteraugli) == (a.ssimulacra2, a.dssim, a.butteraugli) for m in many)
     hd.close()
 
 
