@@ -149,3 +149,75 @@ def test_eval_batch_streams_large_buckets_in_chunks(gpu_ctx, ce, workloads):
             r, t, w, h = pairs[int(k)]
             solo = gpu_ctx.calculate_metrics(r, t, w, h, cfg)
             assert (out[int(k)].ssimulacra2, out[int(k)].psnr) == (solo.ssimulacra2, solo.psnr), (rnd, int(k))
+
+
+def test_eval_batch_route_soak_mixed_shapes_memory_kinds_and_budgets(gpu_ctx, ce, workloads):
+    """The host-buffer route under random conditions (fixed seed): grids that mix two or three shapes, references with 1-9
+    distorted images, page-locked / ordinary / mixed source memory, chunk budgets from "everything in one chunk" down to three
+    pairs (ramped chunk sizes, ring slots reused while later chunks are in flight, two DMA streams, work lists rebuilt when a
+    slot's pair count changes), the same context reused call after call.  Pairs never interact, so every score must equal -
+    exactly - the one the same pair gets alone in a one-pair call."""
+    import os
+
+    rng = np.random.default_rng(4242)
+    cfg = ce.MetricConfig.all()
+    shapes = [(96, 64), (64, 96), (130, 50), (72, 72)]
+    pool = {}  # (shape, seed, q) -> (reference, distorted, scores of the pair alone)
+
+    def alone(shape, seed, q):
+        key = (shape, seed, q)
+        if key not in pool:
+            w, h = shape
+            ref = workloads.make_reference(w, h, 7000 + seed)
+            t = workloads.distort(ref, q)
+            m = gpu_ctx.calculate_metrics(ref, t, w, h, cfg)
+            pool[key] = (ref, t, (m.psnr, m.ssimulacra2, m.dssim, m.butteraugli))
+        return pool[key]
+    saved = os.environ.get("CE_EVAL_BATCH_BYTES")
+    try:
+        for it in range(48):
+            use = [shapes[i] for i in rng.choice(len(shapes), size=int(rng.integers(1, 4)), replace=False)]
+            cells = []
+            for shape in use:
+                for seed in rng.choice(12, size=int(rng.integers(1, 7)), replace=False):
+                    for q in rng.choice([20, 35, 50, 65, 80, 90, 95, 97, 99], size=int(rng.integers(1, 10)), replace=False):
+                        cells.append((shape, int(seed), int(q)))
+            order = rng.permutation(len(cells))
+            cells = [cells[i] for i in order]
+            kind = ["pinned", "pageable", "mixed"][it % 3]
+            n_bytes = sum(2 * s[0] * s[1] * 3 for s, _, _ in cells)
+            slab = gpu_ctx.host_buffer(n_bytes) if kind != "pageable" else None
+            off, refs_placed, items, want = 0, {}, [], []
+            for shape, seed, q in cells:
+                ref, t, sc = alone(shape, seed, q)
+                w, h = shape
+                pin = kind == "pinned" or (kind == "mixed" and (seed + q) % 2 == 0)
+                if (shape, seed, pin) not in refs_placed:  # one buffer per reference: its pairs share the upload
+                    if pin:
+                        v = slab[off:off + ref.size]
+                        v[:] = ref.reshape(-1)
+                        off += ref.size
+                    else:
+                        v = ref.reshape(-1).copy()
+                    refs_placed[(shape, seed, pin)] = v
+                if pin:
+                    tv = slab[off:off + t.size]
+                    tv[:] = t.reshape(-1)
+                    off += t.size
+                else:
+                    tv = t.reshape(-1).copy()
+                items.append((refs_placed[(shape, seed, pin)], tv, w, h))
+                want.append(sc)
+            budget = [None, 3, 8, 20][int(rng.integers(0, 4))]
+            if budget is None:
+                os.environ.pop("CE_EVAL_BATCH_BYTES", None)
+            else:
+                per_pair = max(ce.estimate_batch_bytes(w_, h_, 2, 2, cfg) - ce.estimate_batch_bytes(w_, h_, 1, 1, cfg) for w_, h_ in use)
+                os.environ["CE_EVAL_BATCH_BYTES"] = str(per_pair * budget)
+            got = [(s.psnr, s.ssimulacra2, s.dssim, s.butteraugli) for s in gpu_ctx.eval_batch(items, cfg)]
+            assert got == want, (it, kind, budget, len(items))
+    finally:
+        if saved is None:
+            os.environ.pop("CE_EVAL_BATCH_BYTES", None)
+        else:
+            os.environ["CE_EVAL_BATCH_BYTES"] = saved
