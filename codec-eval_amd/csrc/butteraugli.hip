@@ -117,7 +117,10 @@ __device__ __forceinline__ float border_scale(const blur_kernel &bk, int pos, in
 // is one v_pk_mul_f32 + one v_pk_add_f32 (two IEEE multiplies / adds: bit-identical to the scalar tap loop, taps
 // still summed in ascending order).
 typedef float ba_f2 __attribute__((ext_vector_type(2)));
-constexpr int BH_TILES = 4;  // 8-row tiles per block of the row blur
+#ifndef CE_BH_TILES
+#define CE_BH_TILES 4
+#endif
+constexpr int BH_TILES = CE_BH_TILES;  // 8-row tiles per block of the row blur
 
 template <int LEN>
 __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in, float *__restrict__ out, geom g, plane_sel si,
@@ -153,6 +156,14 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
         }
     };
     const int r = threadIdx.x >> 5, cx = threadIdx.x & 31, gx0 = x0 + 8 * cx;
+    // The border scale of a column is the same for every row: each thread forms ONE column's scale (the select chain of
+    // border_scale is ~50 instructions) and the block shares the 256 of them through LDS, instead of every thread forming
+    // the eight of its own outputs (~700 of the ~3 300 instructions a thread executed per block: profiles/r03_experiments.md 22).
+    __shared__ __attribute__((aligned(16))) float s_scale[TW];
+    {
+        const int gx = x0 + (int)threadIdx.x;
+        s_scale[threadIdx.x] = gx < (int)g.w ? border_scale<LEN>(bk, gx, (int)g.w, inv_wsum) : 0.0f;
+    }
     constexpr int NV = BW_OUT + LEN - 1, NP = (NV + 1) / 2;
     const float *row = &tile[r * ROWF + 9 * cx];  // element j of the window sits at j + SH + ((j + SH) >> 3)
     auto at = [&](int j) { return row[(j + SH) + ((j + SH) >> 3)]; };
@@ -197,8 +208,8 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_h(const float *__restrict__ in,
                 sum = sum + prod;
 #endif
             }
-            res[2 * op] = sum.x * border_scale<LEN>(bk, gx0 + 2 * op, (int)g.w, inv_wsum);
-            res[2 * op + 1] = sum.y * border_scale<LEN>(bk, gx0 + 2 * op + 1, (int)g.w, inv_wsum);
+            res[2 * op] = sum.x * s_scale[8 * cx + 2 * op];  // written before the tile's first barrier
+            res[2 * op + 1] = sum.y * s_scale[8 * cx + 2 * op + 1];
         }
         if (gx0 + BW_OUT <= (int)g.w) {  // rows are 128-byte aligned and gx0 is a multiple of 8
             *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
@@ -498,13 +509,17 @@ __global__ __launch_bounds__(TPB) void k_ba_blur_v_split(const float *__restrict
     // reads for four outputs); its column group is the same in every row it visits (TPB is a multiple of TW / 4)
     constexpr int S0 = LEFT - off, NW = (S0 + 3 + LEN + 3) / 4;
     const int rc4 = 4 * ((int)threadIdx.x % (TW / 4));
-    float scale_x[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) scale_x[k] = (HV && x0 + rc4 + k < (int)g.w) ? border_scale<LEN>(bk, x0 + rc4 + k, (int)g.w, inv_wsum) : 0.0f;
+    // the row pass's border scale of a column: one thread per column forms it, the block shares the 64 through LDS (k_ba_blur_h)
+    __shared__ __attribute__((aligned(16))) float s_sx[HV ? TW : 4];
+    if (HV && threadIdx.x < TW)
+        s_sx[threadIdx.x] = x0 + (int)threadIdx.x < (int)g.w ? border_scale<LEN>(bk, x0 + (int)threadIdx.x, (int)g.w, inv_wsum) : 0.0f;
+    float scale_x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     fetch(0);
     if (HV) {
         stash();
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) scale_x[k] = s_sx[rc4 + k];
     }
 #pragma unroll
     for (int q = 0; q < NP; q++) {
