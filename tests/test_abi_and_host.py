@@ -77,6 +77,10 @@ def test_no_cpu_fallback_without_gpu(ce):
     a = np.zeros(8 * 8 * 3, np.uint8)
     out = ctypes.c_double()
     assert ce.lib().ce_calculate_psnr(None, a.ctypes.data, a.size, a.ctypes.data, a.size, 8, 8, ctypes.byref(out)) == ce.CE_ERR_INVALID_ARG
+    # the page-locked allocator needs a context too; freeing nothing is fine
+    p = ctypes.c_void_p()
+    assert ce.lib().ce_host_alloc(None, 4096, ctypes.byref(p)) == ce.CE_ERR_INVALID_ARG and not p.value
+    assert ce.lib().ce_host_free(None, None) == ce.CE_OK
 
 
 def test_product_never_touches_the_oracle():
